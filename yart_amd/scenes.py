@@ -1,0 +1,583 @@
+"""Deterministic synthetic scene generators (no assets ship with the reference:
+its ``models/`` and ``hdris/`` are git-ignored).
+
+Each generator returns ``(Scene, params_dict)`` where ``params_dict`` holds the
+camera / render settings of the BASELINE.json configuration it stands for, in
+the vocabulary of ``oracle/params.hpp``.
+
+* :func:`cornell`       — C1/C2: single-mesh Cornell box with a quad emitter.
+* :func:`material_test` — small scene exercising every lobe, texture type, alpha
+  cut-outs, normal maps, nested node transforms and an env map.
+* :func:`heightfield`   — Cornell + 256x256 height field (131k triangles), the
+  probe scene of BASELINE.md §2.
+* :func:`sponza_class`  — C3/C4: env-lit atrium, ≈262k triangles, textured.
+* :func:`mclaren_class` — C5: clearcoat / thin-glass / chrome body with DoF.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .yscn import (LIGHT_IMAGE_INF, TEX_LINEAR, TEX_NONCOLOR, TEX_SRGB, Light, Material, Mesh,
+                   Scene, Texture, trs)
+
+
+# --------------------------------------------------------------------------
+# geometry helpers — every helper returns (positions, normals, tangents, uvs, tris)
+# --------------------------------------------------------------------------
+class MeshBuilder:
+    def __init__(self):
+        self.p, self.n, self.t, self.uv, self.f = [], [], [], [], []
+        self.nv = 0
+
+    def add(self, p, n, t, uv, tris, material):
+        p = np.asarray(p, np.float32).reshape(-1, 3)
+        k = len(p)
+        self.p.append(p)
+        self.n.append(np.broadcast_to(np.asarray(n, np.float32), (k, 3)).copy())
+        if t is None:
+            t = np.zeros((k, 4), np.float32)
+        self.t.append(np.broadcast_to(np.asarray(t, np.float32), (k, 4)).copy())
+        if uv is None:
+            uv = np.zeros((k, 2), np.float32)
+        self.uv.append(np.asarray(uv, np.float32).reshape(k, 2))
+        tris = np.asarray(tris, np.uint32).reshape(-1, 3) + np.uint32(self.nv)
+        mat = np.full((len(tris), 1), material, np.uint32)
+        self.f.append(np.concatenate([tris, mat], axis=1))
+        self.nv += k
+
+    def quad(self, p0, p1, p2, p3, material, uv_scale=1.0):
+        """p0..p3 counter-clockwise seen from the front; flat normal."""
+        p = np.asarray([p0, p1, p2, p3], np.float64)
+        e1, e2 = p[1] - p[0], p[3] - p[0]
+        n = np.cross(e1, e2); n /= np.linalg.norm(n)
+        tg = e1 / np.linalg.norm(e1)
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32) * uv_scale
+        self.add(p, n, [*tg, 1.0], uv, [[0, 1, 2], [0, 2, 3]], material)
+
+    def box(self, lo, hi, material, rot_y=0.0, centre=None):
+        lo = np.asarray(lo, np.float64); hi = np.asarray(hi, np.float64)
+        c = (lo + hi) / 2 if centre is None else np.asarray(centre, np.float64)
+        h = (hi - lo) / 2
+        cs, sn = math.cos(rot_y), math.sin(rot_y)
+        R = np.array([[cs, 0, sn], [0, 1, 0], [-sn, 0, cs]])
+
+        def P(x, y, z):
+            return R @ (np.array([x, y, z]) * h) + c
+        faces = [
+            [P(-1, -1, 1), P(1, -1, 1), P(1, 1, 1), P(-1, 1, 1)],      # +z
+            [P(1, -1, -1), P(-1, -1, -1), P(-1, 1, -1), P(1, 1, -1)],  # -z
+            [P(1, -1, 1), P(1, -1, -1), P(1, 1, -1), P(1, 1, 1)],      # +x
+            [P(-1, -1, -1), P(-1, -1, 1), P(-1, 1, 1), P(-1, 1, -1)],  # -x
+            [P(-1, 1, 1), P(1, 1, 1), P(1, 1, -1), P(-1, 1, -1)],      # +y
+            [P(-1, -1, -1), P(1, -1, -1), P(1, -1, 1), P(-1, -1, 1)],  # -y
+        ]
+        for q in faces:
+            self.quad(*q, material)
+
+    def grid(self, fn, nu, nv, material, uv_scale=(1.0, 1.0), flip=False):
+        """Parametric surface fn(u, v) -> (x, y, z) on an (nu+1) x (nv+1) vertex
+        lattice with smooth normals/tangents from finite differences."""
+        u = np.linspace(0.0, 1.0, nu + 1); v = np.linspace(0.0, 1.0, nv + 1)
+        U, V = np.meshgrid(u, v, indexing="xy")            # (nv+1, nu+1)
+        P = np.stack(fn(U, V), axis=-1).astype(np.float64)
+        eps = 1e-4
+        Pu = (np.stack(fn(np.clip(U + eps, 0, 1), V), -1) - np.stack(fn(np.clip(U - eps, 0, 1), V), -1))
+        Pv = (np.stack(fn(U, np.clip(V + eps, 0, 1)), -1) - np.stack(fn(U, np.clip(V - eps, 0, 1)), -1))
+        N = np.cross(Pu, Pv)
+        if flip: N = -N
+        ln = np.linalg.norm(N, axis=-1, keepdims=True); ln[ln == 0] = 1
+        N = N / ln
+        T = Pu / np.maximum(np.linalg.norm(Pu, axis=-1, keepdims=True), 1e-20)
+        T4 = np.concatenate([T, np.ones_like(T[..., :1])], -1)
+        UV = np.stack([U * uv_scale[0], V * uv_scale[1]], -1)
+        idx = np.arange((nu + 1) * (nv + 1)).reshape(nv + 1, nu + 1)
+        a, b, c, d = idx[:-1, :-1], idx[:-1, 1:], idx[1:, 1:], idx[1:, :-1]
+        if flip:
+            tris = np.stack([np.stack([a, c, b], -1), np.stack([a, d, c], -1)], -2)
+        else:
+            tris = np.stack([np.stack([a, b, c], -1), np.stack([a, c, d], -1)], -2)
+        self.add(P.reshape(-1, 3), N.reshape(-1, 3), T4.reshape(-1, 4), UV.reshape(-1, 2),
+                 tris.reshape(-1, 3), material)
+
+    def sphere(self, centre, radius, material, nu=32, nv=16, uv_scale=(1.0, 1.0)):
+        cx, cy, cz = centre
+
+        def fn(U, V):
+            phi = U * 2 * np.pi; th = V * np.pi
+            return (cx + radius * np.sin(th) * np.cos(phi), cy + radius * np.cos(th),
+                    cz + radius * np.sin(th) * np.sin(phi))
+        # analytic normals/tangents (finite differences degenerate at the poles)
+        u = np.linspace(0.0, 1.0, nu + 1); v = np.linspace(0.0, 1.0, nv + 1)
+        U, V = np.meshgrid(u, v, indexing="xy")
+        phi = U * 2 * np.pi; th = V * np.pi
+        N = np.stack([np.sin(th) * np.cos(phi), np.cos(th), np.sin(th) * np.sin(phi)], -1)
+        P = np.asarray(centre) + radius * N
+        T = np.stack([-np.sin(phi), np.zeros_like(phi), np.cos(phi)], -1)
+        T4 = np.concatenate([T, np.ones_like(T[..., :1])], -1)
+        UV = np.stack([U * uv_scale[0], V * uv_scale[1]], -1)
+        idx = np.arange((nu + 1) * (nv + 1)).reshape(nv + 1, nu + 1)
+        a, b, c, d = idx[:-1, :-1], idx[:-1, 1:], idx[1:, 1:], idx[1:, :-1]
+        tris = np.stack([np.stack([a, c, b], -1), np.stack([a, d, c], -1)], -2)
+        self.add(P.reshape(-1, 3), N.reshape(-1, 3), T4.reshape(-1, 4), UV.reshape(-1, 2),
+                 tris.reshape(-1, 3), material)
+
+    def build(self) -> Mesh:
+        return Mesh(np.concatenate(self.p), np.concatenate(self.n), np.concatenate(self.t),
+                    np.concatenate(self.uv), np.concatenate(self.f))
+
+
+# --------------------------------------------------------------------------
+# procedural textures (stored in the post-load form the reference keeps)
+# --------------------------------------------------------------------------
+def _srgb_store(linear):
+    """linear [0,1] -> byte holding sqrt(linear) (gamma-2), as texture.hpp:78-84 re-encodes."""
+    return np.clip(np.sqrt(np.clip(linear, 0, 1)) * 255.0, 0, 255).astype(np.uint8)
+
+
+def _noise(size, seed, octaves=4):
+    rng = np.random.RandomState(seed)
+    out = np.zeros((size, size), np.float64)
+    for o in range(octaves):
+        n = 4 << o
+        g = rng.rand(n, n)
+        reps = size // n
+        up = np.kron(g, np.ones((reps, reps)))
+        # cheap smoothing: average with rolled copies
+        up = (up + np.roll(up, reps // 2, 0) + np.roll(up, reps // 2, 1)) / 3
+        out += up / (1 << o)
+    out -= out.min(); out /= out.max()
+    return out
+
+
+def tex_base_color(size, seed, c0, c1, alpha=None):
+    n = _noise(size, seed)
+    yy, xx = np.mgrid[0:size, 0:size]
+    brick = (((yy // (size // 16)) + (xx // (size // 8))) % 2) * 0.25
+    m = np.clip(n * 0.75 + brick, 0, 1)[..., None]
+    rgb = np.asarray(c0) * (1 - m) + np.asarray(c1) * m
+    a = np.full((size, size, 1), 255, np.uint8) if alpha is None else alpha[..., None]
+    return Texture(np.concatenate([_srgb_store(rgb), a], -1), TEX_SRGB)
+
+
+def tex_alpha_leaves(size, seed):
+    """alpha cut-out pattern (foliage-like): discs on a lattice + noise."""
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    cell = size / 8
+    dx = (xx % cell) - cell / 2; dy = (yy % cell) - cell / 2
+    r = np.sqrt(dx * dx + dy * dy) / (cell / 2)
+    n = _noise(size, seed)
+    a = np.clip((0.95 - r + 0.3 * (n - 0.5)) * 6.0, 0, 1)
+    return (a * 255).astype(np.uint8)
+
+
+def tex_metal_rough(size, seed, rough=(0.3, 0.9), metal=(0.0, 0.0)):
+    n = _noise(size, seed)
+    r = rough[0] + (rough[1] - rough[0]) * n
+    m = metal[0] + (metal[1] - metal[0]) * (n > 0.5)
+    return Texture(np.stack([np.clip(r * 255, 0, 255), np.clip(m * 255, 0, 255)], -1).astype(np.uint8),
+                   TEX_NONCOLOR)
+
+
+def tex_normal(size, seed, strength=0.6):
+    h = _noise(size, seed)
+    gx = (np.roll(h, -1, 1) - np.roll(h, 1, 1)) * strength * size / 64
+    gy = (np.roll(h, -1, 0) - np.roll(h, 1, 0)) * strength * size / 64
+    n = np.stack([-gx, -gy, np.ones_like(h)], -1)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    return Texture(np.clip((n * 0.5 + 0.5) * 255, 0, 255).astype(np.uint8), TEX_NONCOLOR)
+
+
+def tex_mono(size, seed, lo=0.0, hi=1.0):
+    n = _noise(size, seed)
+    return Texture(np.clip((lo + (hi - lo) * n) * 255, 0, 255).astype(np.uint8)[..., None], TEX_NONCOLOR)
+
+
+def sky_octahedral(size, sun_dir=(0.35, 0.8, 0.25), sun_power=60.0, turbidity=1.0):
+    """Procedural sky + sun in the octahedral layout ImageInfiniteLight expects
+    (reference math.hpp:151-179 / light.cpp:137-238)."""
+    v, u = np.mgrid[0:size, 0:size].astype(np.float64)
+    u = (u + 0.5) / size; v = (v + 0.5) / size
+    x = 2 * u - 1; z = 2 * v - 1
+    y = 1 - (np.abs(x) + np.abs(z))
+    neg = y < 0
+    xo = x.copy()
+    x = np.where(neg, (1 - np.abs(z)) * np.sign(x + 1e-30), x)
+    z = np.where(neg, (1 - np.abs(xo)) * np.sign(z + 1e-30), z)
+    d = np.stack([x, y, z], -1); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    s = np.asarray(sun_dir, np.float64); s /= np.linalg.norm(s)
+    up = np.clip(d[..., 1], -1, 1)
+    horizon = np.exp(-np.abs(up) * 4.0)
+    sky = (np.array([0.25, 0.45, 0.95]) * (0.35 + 0.65 * np.clip(up, 0, 1))[..., None]
+           + np.array([0.9, 0.85, 0.75]) * horizon[..., None] * 0.6) * turbidity
+    ground = np.array([0.18, 0.16, 0.14]) * (0.3 + 0.2 * horizon)[..., None]
+    rgb = np.where((up > 0)[..., None], sky, ground)
+    cs = np.clip((d * s).sum(-1), -1, 1)
+    sun = np.exp((cs - 1.0) * 900.0) * sun_power + np.exp((cs - 1.0) * 30.0) * 1.5
+    rgb = rgb + sun[..., None] * np.array([1.0, 0.93, 0.8])
+    return Texture(rgb.astype(np.float32), TEX_LINEAR)
+
+
+# --------------------------------------------------------------------------
+# scenes
+# --------------------------------------------------------------------------
+def _white(**kw):
+    return Material(base=(0.73, 0.73, 0.73), roughness=1.0, **kw)
+
+
+def cornell(width=256, height=256, spp=16, depth=4):
+    """BASELINE configs[0]/[1]: Cornell-style single mesh, camera preset of
+    reference main.cpp:36."""
+    s = Scene()
+    white = s.add_material(_white())
+    red = s.add_material(Material(base=(0.65, 0.05, 0.05), roughness=1.0))
+    green = s.add_material(Material(base=(0.12, 0.45, 0.15), roughness=1.0))
+    light = s.add_material(Material(base=(0.78, 0.78, 0.78), roughness=1.0, emission=(15.0, 15.0, 15.0)))
+    b = MeshBuilder()
+    L, H = 5.0, 10.0
+    b.quad((-L, 0, L), (L, 0, L), (L, 0, -L), (-L, 0, -L), white)          # floor (+y)
+    b.quad((-L, H, -L), (L, H, -L), (L, H, L), (-L, H, L), white)          # ceiling (-y)
+    b.quad((-L, 0, -L), (L, 0, -L), (L, H, -L), (-L, H, -L), white)        # back (+z)
+    b.quad((-L, 0, L), (-L, 0, -L), (-L, H, -L), (-L, H, L), red)          # left (+x)
+    b.quad((L, 0, -L), (L, 0, L), (L, H, L), (L, H, -L), green)            # right (-x)
+    e = 1.5
+    b.quad((-e, H - 0.01, -e), (e, H - 0.01, -e), (e, H - 0.01, e), (-e, H - 0.01, e), light)
+    b.box((-3.2, 0, -3.4), (-0.2, 6.0, -0.4), white, rot_y=0.3)
+    b.box((0.6, 0, 0.2), (3.6, 3.0, 3.2), white, rot_y=-0.31)
+    s.add_node(s.add_mesh(b.build()))
+    s.create_area_lights()
+    p = dict(size=(width, height), spp=spp, depth=depth, focal=35.0, fnumber=0.0,
+             eye=(0.0, 5.0, 15.0), target=(0.0, 5.0, 0.0), up=(0.0, 1.0, 0.0), exposure=0.0,
+             background=(0.0, 0.0, 0.0))
+    return s, p
+
+
+def material_test(width=192, height=128, spp=16, depth=6, tex=64):
+    """Every lobe / texture type / quirk in one small scene: metallic (rough,
+    smooth, anisotropic), rough + smooth dielectric (thin and refractive with
+    volume absorption), glossy-diffuse with all texture kinds, clearcoat,
+    emissive-textured panel, alpha cut-out quad in front of a light, nested node
+    transforms (scaled, rotated instance of a shared mesh), an area light and an
+    env map, DoF with a polygonal aperture."""
+    s = Scene()
+    t_base = s.add_texture(tex_base_color(tex, 1, (0.7, 0.25, 0.15), (0.9, 0.8, 0.6)))
+    t_leaf = s.add_texture(tex_base_color(tex, 2, (0.1, 0.4, 0.1), (0.3, 0.6, 0.2),
+                                          alpha=tex_alpha_leaves(tex, 3)))
+    t_mr = s.add_texture(tex_metal_rough(tex, 4, (0.15, 0.8), (0.0, 1.0)))
+    t_nrm = s.add_texture(tex_normal(tex, 5))
+    t_tr = s.add_texture(tex_mono(tex, 6, 0.2, 1.0))
+    t_cc = s.add_texture(tex_mono(tex, 7, 0.3, 1.0))
+    t_em = s.add_texture(Texture(_srgb_store(np.stack([_noise(tex, 8)] * 3, -1)), TEX_SRGB))
+    t_sky = s.add_texture(sky_octahedral(32, sun_power=20.0))
+
+    M = s.add_material
+    floor = M(Material(base=(1, 1, 1), roughness=1.0, tex_base=t_base, tex_mr=t_mr, tex_normal=t_nrm))
+    mats = [
+        M(Material(base=(0.95, 0.64, 0.54), metallic=1.0, roughness=0.35)),                 # copper
+        M(Material(base=(0.9, 0.9, 0.9), metallic=1.0, roughness=0.0)),                     # mirror
+        M(Material(base=(1.0, 0.78, 0.34), metallic=1.0, roughness=0.4, anisotropic=0.8,
+                   aniso_rotation=0.6)),                                                    # brushed gold
+        M(Material(base=(0.9, 0.95, 1.0), transmission=1.0, roughness=0.25, ior=1.45,
+                   thin_transmission=True)),                                                # thin frosted
+        M(Material(base=(1.0, 1.0, 1.0), transmission=1.0, roughness=0.0, ior=1.5,
+                   volume_color=(0.6, 0.9, 0.7), volume_density=0.8)),                      # solid glass
+        M(Material(base=(0.9, 0.9, 1.0), transmission=0.9, roughness=0.3, ior=1.33,
+                   tex_transmission=t_tr)),                                                 # rough refractive
+        M(Material(base=(0.8, 0.1, 0.1), roughness=0.5, clearcoat=1.0, clearcoat_roughness=0.03)),
+        M(Material(base=(0.1, 0.2, 0.8), roughness=0.6, metallic=0.5, clearcoat=0.8,
+                   clearcoat_roughness=0.2, tex_clearcoat=t_cc)),
+        M(Material(base=(0.8, 0.8, 0.8), roughness=0.0)),                                   # smooth plastic
+        M(Material(base=(1, 1, 1), roughness=0.7, tex_base=t_base, tex_mr=t_mr)),
+    ]
+    leaf = M(Material(base=(1, 1, 1), roughness=0.8, tex_base=t_leaf))
+    glow = M(Material(base=(0.5, 0.5, 0.5), roughness=1.0, emission=(4.0, 3.0, 2.0), tex_emission=t_em))
+    lamp = M(Material(base=(0.8, 0.8, 0.8), roughness=1.0, emission=(20.0, 20.0, 20.0)))
+
+    b = MeshBuilder()
+    b.grid(lambda U, V: ((U - 0.5) * 16, 0 * U, (V - 0.5) * 12), 8, 6, floor, uv_scale=(4, 3), flip=True)
+    for i, m in enumerate(mats):
+        x = -6.0 + 1.35 * i + (0.3 if i % 2 else 0.0)
+        z = -1.5 + 2.0 * (i % 3)
+        b.sphere((x, 0.8, z), 0.8, m, nu=20, nv=10, uv_scale=(2, 1))
+    b.quad((-2, 0.2, 3.0), (2, 0.2, 3.0), (2, 2.4, 3.0), (-2, 2.4, 3.0), leaf, uv_scale=2.0)   # alpha card
+    b.quad((-7.5, 0.5, -5.0), (-4.5, 0.5, -5.0), (-4.5, 2.5, -5.0), (-7.5, 2.5, -5.0), glow)
+    b.quad((-1, 5.0, -1), (1, 5.0, -1), (1, 5.0, 1), (-1, 5.0, 1), lamp)
+    main = s.add_mesh(b.build())
+    s.add_node(main)
+
+    # shared instanced mesh under nested transforms (exercises testNode recursion and
+    # the per-level normal renormalisation, ray-integrator.cpp:26-29, 50-52)
+    bb = MeshBuilder()
+    bb.box((-0.5, 0, -0.5), (0.5, 1, 0.5), mats[0])
+    bb.sphere((0, 1.4, 0), 0.4, mats[6], nu=12, nv=6)
+    inst = s.add_mesh(bb.build())
+    g = s.add_node(-1, 0, *trs((5.0, 0.0, -3.0), (0, 1, 0), 0.5, (1.0, 1.0, 1.0)))
+    s.add_node(inst, g, *trs((0, 0, 0), (0, 1, 0), 0.0, (1.0, 1.5, 1.0)))
+    s.add_node(inst, g, *trs((1.6, 0, 1.0), (0, 0, 1), 0.35, (0.7, 0.7, 0.7)))
+    s.create_area_lights()
+    s.lights.append(Light(LIGHT_IMAGE_INF, texture=t_sky, radius=100.0))
+    p = dict(size=(width, height), spp=spp, depth=depth, focal=35.0, fnumber=2.8, aperture_sides=6,
+             eye=(1.0, 4.0, 11.0), target=(0.0, 0.8, 0.0), up=(0.0, 1.0, 0.0), exposure=0.5,
+             background=(0.02, 0.02, 0.03))
+    return s, p
+
+
+def heightfield(width=256, height=256, spp=16, depth=4, n=256, env=False):
+    """BASELINE.md §2 probe scene: Cornell + n x n height field (2 n^2 triangles)."""
+    s, p = cornell(width, height, spp, depth)
+    white = 0
+    b = MeshBuilder()
+
+    def fn(U, V):
+        x = (U - 0.5) * 9.0; z = (V - 0.5) * 9.0
+        y = 0.6 + 0.5 * np.sin(3.1 * x) * np.cos(2.3 * z) + 0.15 * np.sin(11.0 * x + 5.0 * z)
+        return x, y, z
+    b.grid(fn, n, n, white, flip=True)
+    s.add_node(s.add_mesh(b.build()))
+    s.create_area_lights()
+    if env:
+        t = s.add_texture(sky_octahedral(64))
+        s.lights.append(Light(LIGHT_IMAGE_INF, texture=t, radius=100.0))
+        p["depth"] = 8
+    return s, p
+
+
+def sponza_class(width=1920, height=1080, spp=256, depth=8, detail=1.0, tex=1024, sky=2048):
+    """BASELINE configs[2]/[3]: env-lit two-storey colonnaded atrium, ≈262k
+    triangles at detail=1, 24 materials with procedural base-colour / metal-rough /
+    normal textures, alpha cut-out foliage, cloth banners; no area lights; camera
+    scaled from the reference's "Sponza 2" preset (main.cpp:69-72), 35 mm f/4,
+    exposure +5 EV (main.cpp:32-34) compensated by a dim sky."""
+    s = Scene()
+    rng = np.random.RandomState(1)
+    d = max(detail, 0.05)
+
+    def T(t): return s.add_texture(t)
+    stone_tex = [T(tex_base_color(tex, 10 + i, c0, c1)) for i, (c0, c1) in enumerate([
+        ((0.55, 0.5, 0.42), (0.8, 0.75, 0.65)), ((0.45, 0.4, 0.36), (0.7, 0.62, 0.5)),
+        ((0.6, 0.55, 0.5), (0.85, 0.82, 0.78)), ((0.35, 0.3, 0.28), (0.6, 0.5, 0.42))])]
+    mr_tex = [T(tex_metal_rough(tex, 20 + i, (0.45 + 0.1 * i, 0.95))) for i in range(3)]
+    nrm_tex = [T(tex_normal(tex, 30 + i, 0.4 + 0.2 * i)) for i in range(3)]
+    cloth_tex = [T(tex_base_color(tex, 40 + i, c0, c1)) for i, (c0, c1) in enumerate([
+        ((0.6, 0.05, 0.05), (0.8, 0.2, 0.1)), ((0.05, 0.15, 0.5), (0.1, 0.3, 0.7)),
+        ((0.1, 0.4, 0.1), (0.3, 0.55, 0.2))])]
+    leaf_tex = T(tex_base_color(tex, 50, (0.08, 0.3, 0.06), (0.3, 0.55, 0.15),
+                                alpha=tex_alpha_leaves(tex, 51)))
+    M = s.add_material
+    stone = [M(Material(base=(1, 1, 1), roughness=1.0, tex_base=stone_tex[i % 4], tex_mr=mr_tex[i % 3],
+                        tex_normal=nrm_tex[i % 3])) for i in range(8)]
+    plain = [M(Material(base=tuple(0.4 + 0.5 * rng.rand(3)), roughness=0.5 + 0.5 * rng.rand()))
+             for _ in range(6)]
+    cloth = [M(Material(base=(1, 1, 1), roughness=0.9, tex_base=cloth_tex[i])) for i in range(3)]
+    leaf = M(Material(base=(1, 1, 1), roughness=0.7, tex_base=leaf_tex))
+    bronze = M(Material(base=(0.8, 0.5, 0.25), metallic=1.0, roughness=0.4))
+    tiles = [M(Material(base=(0.9, 0.9, 0.9), roughness=0.15, clearcoat=0.5, clearcoat_roughness=0.05,
+                        tex_base=stone_tex[2])),
+             M(Material(base=(0.3, 0.3, 0.32), roughness=0.25, tex_base=stone_tex[3]))]
+    water = M(Material(base=(0.8, 0.9, 1.0), transmission=1.0, roughness=0.0, ior=1.33,
+                       thin_transmission=True))
+
+    b = MeshBuilder()
+    LX, LZ, H1, H2 = 14.0, 6.0, 5.0, 10.0      # half-length, half-width, storey heights
+    k = lambda v: max(2, int(round(v * math.sqrt(d))))
+
+    # floor tiles (two alternating materials) and ground outside
+    nx, nz = 28, 12
+    for i in range(nx):
+        for j in range(nz):
+            x0 = -LX + 2 * LX * i / nx; x1 = -LX + 2 * LX * (i + 1) / nx
+            z0 = -LZ + 2 * LZ * j / nz; z1 = -LZ + 2 * LZ * (j + 1) / nz
+            b.quad((x0, 0, z1), (x1, 0, z1), (x1, 0, z0), (x0, 0, z0), tiles[(i + j) % 2])
+
+    # outer walls (long sides + short ends), slightly displaced grids so they carry geometry
+    def wall(x0, z0, x1, z1, y0, y1, mat, nu, nv, amp=0.03, flip=False):
+        nrm = np.array([-(z1 - z0), 0.0, (x1 - x0)]); nrm /= np.linalg.norm(nrm)
+
+        def fn(U, V):
+            x = x0 + (x1 - x0) * U; z = z0 + (z1 - z0) * U; y = y0 + (y1 - y0) * V
+            dsp = amp * (np.sin(37 * U * (abs(x1 - x0) + abs(z1 - z0))) * np.sin(29 * V * (y1 - y0)))
+            return x + nrm[0] * dsp, y, z + nrm[2] * dsp
+        b.grid(fn, nu, nv, mat, uv_scale=((abs(x1 - x0) + abs(z1 - z0)) / 4, (y1 - y0) / 4), flip=flip)
+    W = LZ + 3.0
+    wall(-LX - 3, -W, LX + 3, -W, 0, H2 + 2, stone[0], k(220), k(70))
+    wall(LX + 3, W, -LX - 3, W, 0, H2 + 2, stone[1], k(220), k(70))
+    wall(-LX - 3, W, -LX - 3, -W, 0, H2 + 2, stone[2], k(90), k(70))
+    wall(LX + 3, -W, LX + 3, W, 0, H2 + 2, stone[3], k(90), k(70))
+
+    # colonnade: columns (fluted cylinders) + arches, two storeys, both sides
+    ncol = 10
+    for side in (-1, 1):
+        for storey, (y0, y1) in enumerate(((0.0, H1 - 1.2), (H1 + 0.3, H2 - 1.2))):
+            for c in range(ncol + 1):
+                cx = -LX + 2 * LX * c / ncol; cz = side * LZ
+                rad = 0.38 if storey == 0 else 0.3
+                mat = stone[4 + (c + storey) % 4]
+
+                def col(U, V, cx=cx, cz=cz, rad=rad, y0=y0, y1=y1):
+                    phi = U * 2 * np.pi
+                    r = rad * (1.0 + 0.06 * np.cos(12 * phi)) * (1.0 - 0.12 * V + 0.1 * np.exp(-30 * V)
+                                                                + 0.12 * np.exp(-30 * (1 - V)))
+                    return cx + r * np.cos(phi), y0 + (y1 - y0) * V, cz + r * np.sin(phi)
+                b.grid(col, k(48), k(40), mat, uv_scale=(2, 4), flip=True)
+                b.box((cx - 0.5, y0, cz - 0.5), (cx + 0.5, y0 + 0.25, cz + 0.5), mat)
+                b.box((cx - 0.5, y1, cz - 0.5), (cx + 0.5, y1 + 0.2, cz + 0.5), mat)
+            for c in range(ncol):
+                xa = -LX + 2 * LX * c / ncol; xb = -LX + 2 * LX * (c + 1) / ncol
+                cz = side * LZ
+                yb = y1 + 0.2
+
+                def arch(U, V, xa=xa, xb=xb, cz=cz, yb=yb, side=side):
+                    th = np.pi * U
+                    xm = (xa + xb) / 2; rx = (xb - xa) / 2 - 0.3
+                    return (xm - rx * np.cos(th), yb + 1.0 * np.sin(th),
+                            cz + side * (-0.35 + 0.7 * V))
+                b.grid(arch, k(40), k(6), stone[(c + 2) % 4], uv_scale=(3, 0.5), flip=(side < 0))
+                # spandrel wall above the arch
+                wall(xa, cz - side * 0.35, xb, cz - side * 0.35, yb + 1.0, yb + 1.2 + 0.25,
+                     stone[(c + 1) % 4], k(16), k(3), amp=0.0, flip=(side > 0))
+        # gallery floor slabs between the wall and the colonnade
+        za, zb = sorted((side * LZ, side * (LZ + 3.0)))
+        b.box((-LX - 3, H1 - 0.3, za), (LX + 3, H1, zb), plain[1])
+        b.box((-LX - 3, H2 - 0.3, za), (LX + 3, H2, zb), plain[2])
+
+    # cloth banners hanging across the atrium (tessellated, wavy)
+    nb = 7
+    for i in range(nb):
+        x = -LX + 2 * LX * (i + 0.5) / nb
+
+        def ban(U, V, x=x, i=i):
+            z = (U - 0.5) * 2 * (LZ - 0.6)
+            sag = 1.2 * (1 - (2 * U - 1) ** 2)
+            y = H2 - 1.0 - sag - 2.2 * V
+            xx = x + 0.25 * np.sin(6 * U * np.pi + i) * (0.3 + V) + 0.1 * np.sin(9 * V + i)
+            return xx, y, z
+        b.grid(ban, k(70), k(36), cloth[i % 3], uv_scale=(4, 1))
+
+    # ivy / foliage cards with alpha cut-outs on the long walls and columns
+    nl = int(260 * d)
+    for i in range(nl):
+        side = -1 if i % 2 else 1
+        x = -LX + 2 * LX * rng.rand(); y = 0.5 + (H2 - 1.5) * rng.rand()
+        z = side * (W - 0.15 - 0.5 * rng.rand())
+        w, h = 0.8 + 0.8 * rng.rand(), 0.8 + 0.8 * rng.rand()
+        tilt = 0.3 * (rng.rand() - 0.5)
+        if side > 0:
+            b.quad((x + w, y, z + tilt), (x, y, z - tilt), (x, y + h, z - tilt), (x + w, y + h, z + tilt),
+                   leaf, uv_scale=2.0)
+        else:
+            b.quad((x, y, z - tilt), (x + w, y, z + tilt), (x + w, y + h, z + tilt), (x, y + h, z - tilt),
+                   leaf, uv_scale=2.0)
+
+    # central fountain: basin ring, thin water sheet, bronze sphere
+    def basin(U, V):
+        phi = U * 2 * np.pi
+        r = 1.6 + 0.5 * np.sin(np.pi * V)
+        return r * np.cos(phi), 0.05 + 0.9 * V, r * np.sin(phi)
+    b.grid(basin, k(64), k(12), stone[2], uv_scale=(6, 1), flip=True)
+    b.grid(lambda U, V: ((U - 0.5) * 3.0, 0.75 + 0.02 * np.sin(20 * U) * np.cos(17 * V), (V - 0.5) * 3.0),
+           k(40), k(40), water, flip=True)
+    b.sphere((0, 2.0, 0), 0.7, bronze, nu=k(64), nv=k(32))
+    # roof frame: beams leaving the atrium open to the sky
+    for i in range(9):
+        x = -LX + 2 * LX * i / 8
+        b.box((x - 0.15, H2 + 1.2, -W), (x + 0.15, H2 + 1.6, W), plain[3])
+    main = s.add_mesh(b.build())
+    s.add_node(main)
+
+    # instanced urns (shared mesh, per-node transforms) along the galleries
+    ub = MeshBuilder()
+
+    def urn(U, V):
+        phi = U * 2 * np.pi
+        r = 0.18 + 0.22 * np.sin(np.pi * V) ** 1.5 + 0.05 * np.cos(8 * phi) * np.sin(np.pi * V)
+        return r * np.cos(phi), 0.9 * V, r * np.sin(phi)
+    ub.grid(urn, k(40), k(24), bronze, flip=True)
+    um = s.add_mesh(ub.build())
+    grp = s.add_node(-1, 0)
+    for i in range(12):
+        side = -1 if i % 2 else 1
+        x = -LX + 2.0 + (2 * LX - 4.0) * (i // 2) / 5
+        s.add_node(um, grp, *trs((x, H1, side * (LZ + 1.2)), (0, 1, 0), 0.37 * i,
+                                 (1.0 + 0.1 * (i % 3),) * 3))
+
+    s.create_area_lights()
+    t_sky = s.add_texture(sky_octahedral(sky, sun_dir=(0.25, 0.85, 0.35), sun_power=2.2, turbidity=0.035))
+    s.lights.append(Light(LIGHT_IMAGE_INF, texture=t_sky, radius=100.0))
+    p = dict(size=(width, height), spp=spp, depth=depth, focal=35.0, fnumber=4.0,
+             eye=(11.14, 7.02, -1.25), target=(-8.05, 6.0, 0.04), up=(0.0, 1.0, 0.0), exposure=5.0,
+             background=(0.0, 0.0, 0.0))
+    return s, p
+
+
+def mclaren_class(width=3840, height=2160, spp=512, depth=8, detail=1.0, tex=1024, sky=2048):
+    """BASELINE configs[4]: car-like body (superellipsoid panels, wheels, glass
+    canopy) on a ground plane; paint = base + clearcoat, thin glass (the reference
+    loader forces thin transmission, gltf.cpp:105), smooth chrome; env-lit; f/2.8."""
+    s = Scene()
+    d = max(detail, 0.02)
+    k = lambda v: max(3, int(round(v * math.sqrt(d))))
+    M = s.add_material
+    t_ground = s.add_texture(tex_base_color(tex, 60, (0.25, 0.25, 0.27), (0.4, 0.4, 0.42)))
+    t_mr = s.add_texture(tex_metal_rough(tex, 61, (0.35, 0.8)))
+    t_flake = s.add_texture(tex_metal_rough(tex, 62, (0.25, 0.45), (0.0, 1.0)))
+    paint = M(Material(base=(0.75, 0.04, 0.03), roughness=0.45, metallic=0.6, clearcoat=1.0,
+                       clearcoat_roughness=0.03, tex_mr=t_flake))
+    glass = M(Material(base=(0.92, 0.96, 1.0), transmission=1.0, roughness=0.0, ior=1.5,
+                       thin_transmission=True))
+    chrome = M(Material(base=(0.95, 0.95, 0.97), metallic=1.0, roughness=0.0))
+    rubber = M(Material(base=(0.03, 0.03, 0.03), roughness=0.85))
+    carbon = M(Material(base=(0.06, 0.06, 0.07), roughness=0.35, clearcoat=0.6, clearcoat_roughness=0.1))
+    ground = M(Material(base=(1, 1, 1), roughness=1.0, tex_base=t_ground, tex_mr=t_mr))
+    b = MeshBuilder()
+    b.grid(lambda U, V: ((U - 0.5) * 60, 0 * U, (V - 0.5) * 60), k(200), k(200), ground,
+           uv_scale=(20, 20), flip=True)
+
+    def superell(cx, cy, cz, rx, ry, rz, e1, e2, mat, nu, nv):
+        def fn(U, V):
+            phi = (U - 0.5) * 2 * np.pi; th = (V - 0.5) * np.pi
+            f = lambda w, e: np.sign(w) * np.abs(w) ** e
+            return (cx + rx * f(np.cos(th), e1) * f(np.cos(phi), e2),
+                    cy + ry * f(np.sin(th), e1),
+                    cz + rz * f(np.cos(th), e1) * f(np.sin(phi), e2))
+        b.grid(fn, nu, nv, mat, uv_scale=(4, 2))
+    superell(0, 0.55, 0, 2.3, 0.38, 0.95, 0.5, 0.6, paint, k(760), k(380))        # body
+    superell(-0.2, 0.95, 0, 1.0, 0.33, 0.7, 0.7, 0.8, glass, k(360), k(180))      # canopy
+    superell(1.9, 0.4, 0, 0.5, 0.12, 1.0, 0.3, 0.4, carbon, k(200), k(100))       # splitter
+    superell(-2.2, 0.95, 0, 0.25, 0.05, 0.9, 0.3, 0.3, carbon, k(200), k(100))    # wing
+    for sx in (-1.45, 1.45):
+        for sz in (-0.95, 0.95):
+            def tyre(U, V, sx=sx, sz=sz):
+                phi = U * 2 * np.pi; th = V * 2 * np.pi
+                R, r = 0.27, 0.11
+                return (sx + (R + r * np.cos(th)) * np.cos(phi), 0.38 + (R + r * np.cos(th)) * np.sin(phi),
+                        sz + r * 1.3 * np.sin(th))
+            b.grid(tyre, k(200), k(80), rubber)
+            superell(sx, 0.38, sz, 0.2, 0.2, 0.09, 1.0, 1.0, chrome, k(120), k(60))
+    s.add_node(s.add_mesh(b.build()))
+    s.create_area_lights()
+    t_sky = s.add_texture(sky_octahedral(sky, sun_dir=(-0.4, 0.6, 0.5), sun_power=40.0))
+    s.lights.append(Light(LIGHT_IMAGE_INF, texture=t_sky, radius=100.0))
+    p = dict(size=(width, height), spp=spp, depth=depth, focal=35.0, fnumber=2.8,
+             eye=(5.69, 1.4, 2.6), target=(0.0, 0.6, 0.0), up=(0.0, 1.0, 0.0), exposure=0.0,
+             background=(0.0, 0.0, 0.0))
+    return s, p
+
+
+def write_params(path, p, threads=None, probe_pixels=None, **override):
+    """Write an oracle/params.hpp parameter file."""
+    q = dict(p); q.update(override)
+    lines = []
+    for key, val in q.items():
+        if isinstance(val, (tuple, list, np.ndarray)):
+            lines.append(f"{key} " + " ".join(repr(float(v)) if key != "size" else str(int(v)) for v in val))
+        elif isinstance(val, float):
+            lines.append(f"{key} {val!r}")
+        else:
+            lines.append(f"{key} {int(val)}")
+    if threads is not None:
+        lines.append(f"threads {int(threads)}")
+    if probe_pixels is not None:
+        lines.append("probe_pixels " + " ".join(str(int(v)) for xy in probe_pixels for v in xy))
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")

@@ -1,0 +1,173 @@
+/* yart_hip.h — C ABI of the MI355X-native path-tracing integrator (libyart_hip.so).
+ *
+ * The reference (teofum/yart) has no plugin / FFI layer: its seam is the abstract
+ * C++ class yart::Renderer (reference src/core/renderer.hpp:17-104) implemented by
+ * yart::cpu::TileRenderer (src/cpu/tile-renderer.hpp:22-310). This header is what
+ * a binding for that seam calls: plain C, POD structs, caller-owned buffers, no
+ * C++/torch types. INTEGRATION.md shows the adapter class a maintainer of the
+ * reference would add on top of it.
+ *
+ * Every entry point returns 0 on success or a negative YART_E_* code;
+ * yart_hip_last_error() gives the message. There is NO CPU fallback: without a
+ * HIP device every compute entry point fails with YART_E_NO_DEVICE.
+ */
+#ifndef YART_HIP_H
+#define YART_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YART_HIP_ABI_VERSION 1
+
+enum {
+  YART_OK = 0,
+  YART_E_INVALID = -1,    /* bad descriptor (null pointer, index out of range, ...) */
+  YART_E_NO_DEVICE = -2,  /* no usable HIP device */
+  YART_E_HIP = -3,        /* a HIP runtime call failed */
+  YART_E_IO = -4          /* scene file could not be read */
+};
+
+/* Texture as the reference holds it after load (src/core/texture.hpp:21-49):
+ * u8 with 1-4 channels or float RGB; sRGB-typed data is gamma-2 encoded
+ * (texture.hpp:78-84). type: 0 LinearRGB, 1 sRGB, 2 NonColor. */
+typedef struct YartTextureDesc {
+  uint32_t width, height, channels, is_float, type;
+  const void* data;
+} YartTextureDesc;
+
+/* Constructor arguments of ParametricBSDF (src/bsdf/parametric.hpp:16-37);
+ * tex_* are indices into YartSceneDesc.textures or -1. */
+typedef struct YartMaterialDesc {
+  float base[3];
+  float emission[3];
+  float metallic, roughness, transmission, ior;
+  float anisotropic, aniso_rotation, clearcoat, clearcoat_roughness;
+  float normal_scale;
+  uint32_t thin_transmission;
+  float volume_color[3];
+  float volume_density;
+  int32_t tex_base, tex_mr, tex_transmission, tex_normal, tex_clearcoat, tex_emission;
+} YartMaterialDesc;
+
+/* Arguments of Mesh(vertices, vertexData, faces) (src/core/mesh.hpp:54-61) plus the
+ * per-triangle light index the loader assigns (src/gltf/gltf.cpp:299-309). */
+typedef struct YartMeshDesc {
+  uint32_t n_vertices, n_faces;
+  const float* positions;   /* 3 per vertex */
+  const float* normals;     /* 3 per vertex */
+  const float* tangents;    /* 4 per vertex (xyz + handedness) */
+  const float* uvs;         /* 2 per vertex */
+  const uint32_t* faces;    /* 4 per face: i0, i1, i2, material */
+  const int32_t* face_light;/* 1 per face: light index or -1 */
+} YartMeshDesc;
+
+/* Scene-graph node (src/core/scene.hpp:11-64), pre-order, node 0 = root.
+ * fwd / inv: row-major 4x4 Transform matrices (src/math/transform.hpp). */
+typedef struct YartNodeDesc {
+  int32_t parent, mesh;
+  float fwd[16], inv[16];
+} YartNodeDesc;
+
+/* Light (src/core/light.hpp): type 0 AreaLight(tri of mesh, emission, transform),
+ * 1 UniformInfiniteLight(radius, emission), 2 ImageInfiniteLight(radius, float RGB
+ * octahedral texture) with its public `transform`. */
+typedef struct YartLightDesc {
+  uint32_t type;
+  int32_t mesh;
+  uint32_t tri, two_sided;
+  int32_t texture;
+  float radius;
+  float emission[3];
+  float fwd[16], inv[16];
+} YartLightDesc;
+
+typedef struct YartSceneDesc {
+  uint32_t n_textures, n_materials, n_meshes, n_nodes, n_lights;
+  const YartTextureDesc* textures;
+  const YartMaterialDesc* materials;
+  const YartMeshDesc* meshes;
+  const YartNodeDesc* nodes;
+  const YartLightDesc* lights;
+} YartSceneDesc;
+
+/* Camera(imageSize, focalLength, fNumber, sensorSize) + moveAndLookAt + exposure /
+ * apertureSides (src/core/camera.hpp:62-130). */
+typedef struct YartCameraDesc {
+  uint32_t width, height;
+  float focal_length, f_number;
+  float sensor[2];
+  float position[3], target[3], up[3];
+  float exposure;
+  uint32_t aperture_sides;
+} YartCameraDesc;
+
+/* TileRenderer knobs (src/cpu/tile-renderer.hpp:27-32), Renderer::backgroundColor
+ * (src/core/renderer.hpp:52), RayIntegrator::m_maxDepth (src/cpu/ray-integrator.hpp:14).
+ * rank/world_size: this process renders the 64x64 tiles t with t % world_size == rank
+ * (tiles numbered in Morton order) and leaves the other pixels 0. */
+typedef struct YartRenderParams {
+  uint32_t samples, first_wave_samples, max_wave_samples, tile_size, max_depth;
+  float background[3];
+  uint32_t rank, world_size;
+  uint32_t flags;            /* YART_FLAG_* */
+  uint32_t reserved[4];
+} YartRenderParams;
+
+#define YART_FLAG_MEGAKERNEL 1u   /* single-kernel integrator instead of the wavefront pipeline */
+
+/* Renderer::RenderData counters (src/core/renderer.hpp:22-28) + per-stage device time. */
+typedef struct YartStats {
+  uint64_t samples;          /* pixel samples taken by this rank */
+  uint64_t rays;             /* path segments + unoccluded shadow rays (mis-integrator.cpp:22,126) */
+  double ms_total;           /* wall time of the call */
+  double ms_device;          /* HIP-event time of all kernels */
+  double ms_traverse;        /* HIP-event time of the traversal kernels only */
+  uint64_t traversals;       /* rays traced (closest-hit + shadow) */
+  uint64_t box_tests, tri_tests;   /* exact counts when collected (instrumented build), else 0 */
+  uint32_t waves;            /* progressive waves rendered */
+  uint32_t launches_traverse;
+  uint32_t reserved[4];
+} YartStats;
+
+typedef struct YartScene YartScene;
+
+/* Build the device scene (BVH build per mesh, flattening, upload). device < 0: current. */
+int yart_hip_scene_create(const YartSceneDesc* desc, int device, YartScene** out);
+/* Same, from a .yscn container (yart_amd/yscn.py). */
+int yart_hip_scene_load(const char* path, int device, YartScene** out);
+void yart_hip_scene_destroy(YartScene* scene);
+
+/* Blocking render (Renderer::renderSync). out_rgba: caller-owned host buffer of
+ * width*height*4 floats, linear HDR with exposure applied, alpha = 1 — the
+ * reference's m_hdrBuffer (tile-renderer.hpp:93, tonemapper == nullptr). */
+int yart_hip_render(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                    float* out_rgba, YartStats* stats);
+/* Same, writing a DEVICE buffer (e.g. a torch tensor's data_ptr) on `stream`
+ * (hipStream_t, may be NULL); returns after the work has been enqueued and
+ * completed on that stream. */
+int yart_hip_render_device(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                           float* d_out_rgba, void* stream, YartStats* stats);
+
+/* Diagnostics (device code paths, used by the parity tests):
+ * per-sample radiance (before exposure) of n (x, y, sample) triples -> 3 floats each */
+int yart_hip_probe_samples(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                           uint32_t n, const uint32_t* xys, float* out_rgb, uint64_t* out_rays);
+/* closest hit of n world rays (ox,oy,oz,dx,dy,dz) -> 16 floats each:
+ * hit, t, u, v, px,py,pz, nx,ny,nz, tx,ty,tz, triIdx, lightIdx, backSide */
+int yart_hip_probe_hits(YartScene* scene, uint32_t n, const float* rays, float* out);
+/* the BVH the kernels traverse: nodes (8 x u32 each: bounds, left|first, span) and
+ * the index permutation of mesh `mesh` */
+int yart_hip_bvh_info(YartScene* scene, uint32_t mesh, uint32_t* n_nodes, uint32_t* n_tris);
+int yart_hip_bvh_copy(YartScene* scene, uint32_t mesh, uint32_t* nodes_out, uint32_t* indices_out);
+
+const char* yart_hip_last_error(void);
+int yart_hip_abi_version(void);
+int yart_hip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YART_HIP_H */

@@ -332,7 +332,8 @@ static int doKat(const std::string& scenePath, const std::string& paramPath,
     kat::Lcg rng(7);
     for (size_t i = 0; i + 1 < p.probePixels.size(); i += 2) {
       for (int k = 0; k < 4; k++) {
-        float2 uf(rng.next(), rng.next()), ul(rng.next(), rng.next());
+        float a0 = rng.next(), a1 = rng.next(), a2 = rng.next(), a3 = rng.next();   // sequenced draws
+        float2 uf(a0, a1), ul(a2, a3);
         Ray r = cam.getRay({p.probePixels[i], p.probePixels[i + 1]}, uf, ul);
         for (int c = 0; c < 3; c++) out.push_back(r.origin[c]);
         for (int c = 0; c < 3; c++) out.push_back(r.dir[c]);
@@ -390,11 +391,14 @@ static int doKat(const std::string& scenePath, const std::string& paramPath,
       const BSDF& b = *built.materials[m];
       kat::Lcg rng(1000 + uint32_t(m));
       for (int k = 0; k < kat::bsdfCasesPerMaterial; k++) {
-        float3 wo = normalized(float3(rng.sym(), rng.sym(), rng.sym()));
-        float3 wi = normalized(float3(rng.sym(), rng.sym(), rng.sym()));
-        float2 uv(rng.next() * 3.0f - 1.0f, rng.next() * 3.0f - 1.0f);
-        float2 u(rng.next(), rng.next());
-        float uc = rng.next(), uc2 = rng.next();
+        float r[12];
+        for (int q = 0; q < 6; q++) r[q] = rng.sym();       // sequenced draws (argument order is unspecified)
+        for (int q = 6; q < 12; q++) r[q] = rng.next();
+        float3 wo = normalized(float3(r[0], r[1], r[2]));
+        float3 wi = normalized(float3(r[3], r[4], r[5]));
+        float2 uv(r[6] * 3.0f - 1.0f, r[7] * 3.0f - 1.0f);
+        float2 u(r[8], r[9]);
+        float uc = r[10], uc2 = r[11];
         bool reg = k & 1;
         float3 f = b.f(wo, wi, n, t, uv);
         float pdf = b.pdf(wo, wi, n, t, uv);
@@ -431,15 +435,17 @@ static int doKat(const std::string& scenePath, const std::string& paramPath,
       const Light& l = scene.light(li);
       fo.push_back(l.power());
       for (int k = 0; k < 4; k++) {
-        float3 pp(rng.sym() * 4.0f, rng.next() * 8.0f, rng.sym() * 4.0f);
-        float2 u(rng.next(), rng.next());
+        float r0 = rng.sym(), r1 = rng.next(), r2 = rng.sym(), r3 = rng.next(), r4 = rng.next();
+        float3 pp(r0 * 4.0f, r1 * 8.0f, r2 * 4.0f);
+        float2 u(r3, r4);
         LightSample s = l.sample(pp, float3(0, 1, 0), u, 0.0f);
         for (int c = 0; c < 3; c++) fo.push_back(s.Li[c]);
         for (int c = 0; c < 3; c++) fo.push_back(s.wi[c]);
         for (int c = 0; c < 3; c++) fo.push_back(s.p[c]);
         for (int c = 0; c < 3; c++) fo.push_back(s.n[c]);
         fo.push_back(s.pdf);
-        float3 wi = normalized(float3(rng.sym(), rng.sym(), rng.sym()));
+        float w0 = rng.sym(), w1 = rng.sym(), w2 = rng.sym();
+        float3 wi = normalized(float3(w0, w1, w2));
         fo.push_back(l.pdf(wi));
         float3 le = l.Le(octahedralUV(wi));
         for (int c = 0; c < 3; c++) fo.push_back(le[c]);

@@ -1,0 +1,311 @@
+// hostsim.cpp — TEST INFRASTRUCTURE, never part of libyart_hip.so.
+//
+// Compiles the product's device headers (yart_amd/csrc/*.hpp) as plain host C++
+// (YART_HD expands to `inline`) and evaluates the known-answer-test program of
+// oracle/kat_common.hpp with them, so that every device function can be compared
+// bit for bit with the compiled reference (oracle/_ref/yart_ref kat) in the
+// GPU-less build container. It also renders small images on CPU threads with the
+// same per-sample code, which lets `pytest -m "not gpu"` bound the difference
+// between the kernel source and the reference before a GPU is involved.
+// It is not a fallback: the C ABI has no path to this code (tests/test_no_fallback.py
+// checks that the library fails without a device).
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+
+#include "../../oracle/kat_common.hpp"
+#include "../../oracle/params.hpp"
+#include "../../yart_amd/csrc/estimator.hpp"
+#include "../../yart_amd/csrc/host_scene.hpp"
+#include "../../yart_amd/csrc/integrator.hpp"
+#include "../../yart_amd/csrc/scene_file.hpp"
+
+using namespace yart_hip;
+
+static YartCameraDesc cameraDesc(const params::Params& p) {
+  YartCameraDesc c{};
+  c.width = p.width; c.height = p.height; c.focal_length = p.focal; c.f_number = p.fnumber;
+  c.sensor[0] = p.sensor[0]; c.sensor[1] = p.sensor[1];
+  for (int i = 0; i < 3; i++) { c.position[i] = p.eye[i]; c.target[i] = p.target[i]; c.up[i] = p.up[i]; }
+  c.exposure = p.exposure; c.aperture_sides = p.apertureSides;
+  return c;
+}
+
+struct Ctx {
+  HostImage im;
+  SceneDev sc;
+  CameraDev cam;
+  RenderConst rc;
+};
+
+static PathCtx pathCtx(const Ctx& c, uint64_t* stack) {
+  PathCtx px;
+  px.sc = &c.sc;
+  px.sobol = reinterpret_cast<const uint32_t*>(c.sc.lut + LutDev::sobol);
+  px.stk.lds = stack; px.stk.ldsStride = 1; px.stk.ldsDepth = kRefStackDepth;
+  px.stk.spill = nullptr; px.stk.spillStride = 0;
+  px.rc = c.rc;
+  return px;
+}
+
+static int doKat(Ctx& c, const params::Params& p, const std::string& outPath) {
+  kat::Writer w(outPath);
+  {
+    std::vector<uint64_t> h, mb, mo;
+    std::vector<int64_t> l2;
+    for (uint32_t d = 0; d < 48; d++) h.push_back(hashDim(d));
+    for (uint64_t v : kat::mixInputs()) mb.push_back(mixBits(v));
+    for (auto xy : kat::mortonInputs()) mo.push_back(encodeMorton2(xy.first, xy.second));
+    for (float v : kat::log2Inputs()) l2.push_back(log2IntHost(v));
+    w.u64("hash32", h); w.u64("mixbits", mb); w.u64("morton", mo); w.i64("log2int", l2);
+  }
+  const uint32_t* sobol = reinterpret_cast<const uint32_t*>(c.sc.lut + LutDev::sobol);
+  {
+    std::vector<float> out;
+    for (const auto& k : kat::samplerCases()) {
+      SamplerConfig cfg = makeSamplerConfig(k.spp, k.tile);
+      Sampler s;
+      startPixelSample(s, cfg, k.px, k.py, k.sample);
+      for (int q : kat::samplerPattern()) {
+        if (q == 2) { f2 v = get2D(s, cfg, sobol); out.push_back(v.x); out.push_back(v.y); }
+        else out.push_back(get1D(s, cfg));
+      }
+    }
+    w.f32("sampler", out);
+  }
+  {
+    std::vector<float> e, ea, be, bea, ge, gea;
+    const float* lut = c.sc.lut;
+    for (const auto& q : kat::lutInputs()) {
+      e.push_back(ggxE(lut, q.c, q.r));
+      ea.push_back(ggxEavg(lut, q.r));
+      be.push_back(ggxBaseE(lut, q.f0, q.r, q.c));
+      bea.push_back(ggxBaseEavg(lut, q.f0, q.r));
+      ge.push_back(ggxGlassE(lut, q.ior, q.r, std::fabs(q.c)));
+      gea.push_back(0.0f);   // ggxGlassEavg is not on the path (unused by parametric.cpp)
+    }
+    w.f32("ggxE", e); w.f32("ggxEavg", ea); w.f32("ggxBaseE", be);
+    w.f32("ggxBaseEavg", bea); w.f32("ggxGlassE", ge); w.f32("ggxGlassEavg", gea);
+  }
+  {
+    std::vector<float> out;
+    kat::Lcg rng(7);
+    for (size_t i = 0; i + 1 < p.probePixels.size(); i += 2) {
+      for (int k = 0; k < 4; k++) {
+        f2 uf = mk2(0, 0), ul = mk2(0, 0);
+        uf.x = rng.next(); uf.y = rng.next(); ul.x = rng.next(); ul.y = rng.next();
+        f3 o, d;
+        cameraRay(c.cam, p.probePixels[i], p.probePixels[i + 1], uf, ul, o, d);
+        out.push_back(o.x); out.push_back(o.y); out.push_back(o.z);
+        out.push_back(d.x); out.push_back(d.y); out.push_back(d.z);
+      }
+    }
+    w.f32("camera_rays", out);
+  }
+  {
+    std::vector<uint64_t> out;
+    for (size_t m = 0; m < c.im.meshes.size(); m++) {
+      const MeshDev& md = c.im.meshes[m];
+      out.push_back(md.nNodes);
+      out.push_back(kat::fnv1a(c.im.bvhNodes.data() + md.nodeOffset, size_t(md.nNodes) * 32));
+      out.push_back(kat::fnv1a(c.im.bvhIndices[m].data(), c.im.bvhIndices[m].size() * 4));
+    }
+    w.u64("bvh", out);
+  }
+  uint64_t stack[kRefStackDepth];
+  PathCtx px = pathCtx(c, stack);
+  {
+    std::vector<float> fo;
+    std::vector<int64_t> io;
+    for (size_t i = 0; i + 1 < p.probePixels.size(); i += 2) {
+      f3 o, d;
+      cameraRay(c.cam, p.probePixels[i], p.probePixels[i + 1], mk2(0.5f, 0.5f), mk2(0.5f, 0.5f), o, d);
+      HitRec hr; hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
+      f3 att = mk3(1.0f);
+      Sampler dummy; dummy.dim = 0; dummy.morton = 0;
+      AlphaCtx ac; ac.sampler = &dummy; ac.cfg = c.rc.sampler;
+      bool hit = traverseScene<false>(c.sc, o, d, 0.001f, hr, att, px.stk, ac);
+      io.push_back(hit);
+      if (!hit) { io.push_back(-1); io.push_back(-1); io.push_back(0); for (int k = 0; k < 12; k++) fo.push_back(0); continue; }
+      Hit h = finalizeHit(c.sc, hr, o, d);
+      io.push_back(hr.tri); io.push_back(h.lightIdx); io.push_back(h.backSide);
+      fo.push_back(h.t); fo.push_back(h.uv.x); fo.push_back(h.uv.y);
+      fo.push_back(h.p.x); fo.push_back(h.p.y); fo.push_back(h.p.z);
+      fo.push_back(h.n.x); fo.push_back(h.n.y); fo.push_back(h.n.z);
+      fo.push_back(h.tg.x); fo.push_back(h.tg.y); fo.push_back(h.tg.z);
+    }
+    w.i64("hits_i", io); w.f32("hits_f", fo);
+  }
+  {
+    std::vector<float> fo;
+    std::vector<int64_t> io;
+    const f3 n = mk3(0, 0, 1), t = mk3(1, 0, 0);
+    size_t nm = c.im.nMaterials;
+    for (size_t m = 0; m < nm; m++) {
+      const MaterialDev& mt = c.im.materials[m];
+      kat::Lcg rng(1000 + uint32_t(m));
+      for (int k = 0; k < kat::bsdfCasesPerMaterial; k++) {
+        float r[12];
+        for (int q = 0; q < 6; q++) r[q] = rng.sym();
+        for (int q = 6; q < 12; q++) r[q] = rng.next();
+        f3 wo = normalized(mk3(r[0], r[1], r[2]));
+        f3 wi = normalized(mk3(r[3], r[4], r[5]));
+        f2 uv = mk2(r[6] * 3.0f - 1.0f, r[7] * 3.0f - 1.0f);
+        f2 u = mk2(r[8], r[9]);
+        float uc = r[10], uc2 = r[11];
+        bool reg = k & 1;
+        f3 f = bsdfF(c.sc, mt, wo, wi, n, t, uv);
+        float pdf = bsdfPdf(c.sc, mt, wo, wi, n, t, uv);
+        BsdfSample s = bsdfSample(c.sc, mt, wo, n, t, uv, u, uc, uc2, reg);
+        fo.push_back(f.x); fo.push_back(f.y); fo.push_back(f.z);
+        fo.push_back(pdf);
+        io.push_back(s.scatter);
+        fo.push_back(s.f.x); fo.push_back(s.f.y); fo.push_back(s.f.z);
+        fo.push_back(s.Le.x); fo.push_back(s.Le.y); fo.push_back(s.Le.z);
+        fo.push_back(s.wi.x); fo.push_back(s.wi.y); fo.push_back(s.wi.z);
+        fo.push_back(s.pdf); fo.push_back(s.roughness);
+        fo.push_back(matAlpha(c.sc, mt, uv));
+        f3 base = matBase(c.sc, mt, uv);
+        fo.push_back(base.x); fo.push_back(base.y); fo.push_back(base.z);
+        f4 t4; t4.x = 1; t4.y = 0; t4.z = 0; t4.w = 1;
+        f3 sn = bsdfNormal(c.sc, mt, n, t4, uv);
+        fo.push_back(sn.x); fo.push_back(sn.y); fo.push_back(sn.z);
+        f3 att = matAttenuation(mt, uc * 4.0f);
+        fo.push_back(att.x); fo.push_back(att.y); fo.push_back(att.z);
+      }
+      io.push_back((mt.flags & MAT_TRANSPARENT) ? 1 : 0);
+    }
+    w.i64("bsdf_i", io); w.f32("bsdf_f", fo);
+  }
+  {
+    std::vector<float> fo;
+    std::vector<int64_t> io;
+    size_t nl = c.sc.nLights;
+    kat::Lcg rng(4242);
+    for (size_t li : kat::lightSubset(nl)) {
+      const LightDev& l = c.sc.lights[li];
+      fo.push_back(l.power);
+      for (int k = 0; k < 4; k++) {
+        float r0 = rng.sym(), r1 = rng.next(), r2 = rng.sym(), r3 = rng.next(), r4 = rng.next();
+        f3 pp = mk3(r0 * 4.0f, r1 * 8.0f, r2 * 4.0f);
+        f2 u = mk2(r3, r4);
+        LightSample s = lightSample(c.sc, l, pp, u);
+        fo.push_back(s.Li.x); fo.push_back(s.Li.y); fo.push_back(s.Li.z);
+        fo.push_back(s.wi.x); fo.push_back(s.wi.y); fo.push_back(s.wi.z);
+        fo.push_back(s.p.x); fo.push_back(s.p.y); fo.push_back(s.p.z);
+        fo.push_back(s.n.x); fo.push_back(s.n.y); fo.push_back(s.n.z);
+        fo.push_back(s.pdf);
+        float w0 = rng.sym(), w1 = rng.sym(), w2 = rng.sym();
+        f3 wi = normalized(mk3(w0, w1, w2));
+        fo.push_back(lightPdf(c.sc, l, wi));
+        f3 le = lightLe(c.sc, l, octahedralUV(wi));
+        fo.push_back(le.x); fo.push_back(le.y); fo.push_back(le.z);
+      }
+      fo.push_back(lightSamplerP(c.sc, uint32_t(li)));
+    }
+    if (nl > 0) {
+      for (int k = 0; k < 32; k++) {
+        float u = rng.next();
+        float pl;
+        uint32_t which = lightSamplerSample(c.sc, u, pl);
+        io.push_back(which);
+        fo.push_back(pl);
+      }
+    }
+    w.i64("lights_i", io); w.f32("lights_f", fo);
+  }
+  {
+    std::vector<float> rad, pix;
+    uint32_t rays = 0;
+    for (size_t i = 0; i + 1 < p.probePixels.size(); i += 2) {
+      int m = gmonBuckets(int32_t(p.spp));
+      f3 acc[kGmonMax]; uint32_t cnt[kGmonMax];
+      for (int b = 0; b < kGmonMax; b++) { acc[b] = mk3(0); cnt[b] = 0; }
+      for (uint32_t s = 0; s < p.spp; s++) {
+        f3 L = samplePixel(px, c.cam, p.probePixels[i], p.probePixels[i + 1], s, rays);
+        rad.push_back(L.x); rad.push_back(L.y); rad.push_back(L.z);
+        f3 v = L * c.cam.exposureScale;
+        int b = int(s % uint32_t(m));
+        if (gmonAccepts(v)) { acc[b] += v; cnt[b]++; }
+      }
+      f3 v = gmonFinish(acc, cnt, m);
+      pix.push_back(v.x); pix.push_back(v.y); pix.push_back(v.z);
+    }
+    w.f32("radiance", rad); w.f32("gmon", pix);
+    std::vector<uint64_t> rc{rays};
+    w.u64("probe_rays", rc);
+  }
+  w.close();
+  return 0;
+}
+
+static int doRender(Ctx& c, const params::Params& p, const std::string& outPath) {
+  const uint32_t W = p.width, H = p.height;
+  std::vector<float> img(size_t(W) * H * 4, 0.0f);
+  std::atomic<uint32_t> nextRow{0};
+  std::atomic<uint64_t> totalRays{0};
+  unsigned nt = p.threads ? p.threads : std::thread::hardware_concurrency();
+  auto t0 = std::chrono::high_resolution_clock::now();
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([&] {
+      uint64_t stack[kRefStackDepth];
+      PathCtx px = pathCtx(c, stack);
+      uint32_t rays = 0;
+      int m = gmonBuckets(int32_t(p.spp));
+      for (;;) {
+        uint32_t y = nextRow++;
+        if (y >= H) break;
+        for (uint32_t x = 0; x < W; x++) {
+          f3 acc[kGmonMax]; uint32_t cnt[kGmonMax];
+          for (int b = 0; b < kGmonMax; b++) { acc[b] = mk3(0); cnt[b] = 0; }
+          for (uint32_t s = 0; s < p.spp; s++) {
+            f3 v = samplePixel(px, c.cam, x, y, s, rays) * c.cam.exposureScale;
+            int b = int(s % uint32_t(m));
+            if (gmonAccepts(v)) { acc[b] += v; cnt[b]++; }
+          }
+          f3 v = gmonFinish(acc, cnt, m);
+          float* o = &img[(size_t(y) * W + x) * 4];
+          // single wave: hdr = hdr*0 + wave*1 (tile-renderer.hpp:220-232)
+          o[0] = 0.0f * 0.0f + v.x * 1.0f; o[1] = 0.0f * 0.0f + v.y * 1.0f; o[2] = 0.0f * 0.0f + v.z * 1.0f;
+          o[3] = 1.0f;
+        }
+      }
+      totalRays += rays;
+    });
+  for (auto& t : th) t.join();
+  double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+  FILE* f = std::fopen(outPath.c_str(), "wb");
+  if (!f) return 2;
+  std::fwrite(img.data(), 4, img.size(), f);
+  std::fclose(f);
+  std::printf("{\"rays\": %llu, \"seconds\": %.6f, \"msamples_per_s\": %.6f, \"threads\": %u}\n",
+              (unsigned long long) totalRays.load(), sec, double(W) * H * p.spp / sec * 1e-6, nt);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc != 5) {
+    std::fprintf(stderr, "usage: hostsim kat|render <scene.yscn> <params.txt> <out>\n");
+    return 1;
+  }
+  try {
+    auto loaded = loadSceneFile(argv[2]);
+    auto p = params::load(argv[3]);
+    Ctx c;
+    c.im = buildHostImage(loaded->desc);
+    c.sc = c.im.view();
+    c.cam = makeCamera(cameraDesc(p));
+    c.rc.sampler = makeSamplerConfig(p.spp, p.tile);
+    c.rc.maxDepth = p.depth;
+    c.rc.background = mk3(p.background[0], p.background[1], p.background[2]);
+    std::string mode = argv[1];
+    if (mode == "kat") return doKat(c, p, argv[4]);
+    if (mode == "render") return doRender(c, p, argv[4]);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "hostsim: %s\n", e.what());
+    return 2;
+  }
+  return 1;
+}

@@ -1,0 +1,390 @@
+// host_scene.hpp — host-side preparation of the flattened scene image:
+// BVH build, leaf records, scene-graph flattening, material constants, light
+// tables and environment-map distributions. Everything here runs once per scene
+// (the reference does the same work in its constructors: Mesh::Mesh mesh.hpp:54-61,
+// Node::appendChild scene.hpp:48-52, ParametricBSDF ctor parametric.cpp:11-68,
+// AreaLight ctor light.cpp:16-34, ImageInfiniteLight ctor light.cpp:137-197,
+// PowerLightSampler::init light-sampler.cpp:32-50, Camera::calcDerivedProperties
+// camera.hpp:25-59) with the same float arithmetic, so the kernels start from
+// bit-identical constants.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/yart_hip.h"
+#include "bvh_build.hpp"
+#include "sampler.hpp"
+#include "scene_types.hpp"
+
+namespace yart_hip {
+
+struct HostImage {
+  std::vector<BvhNode> bvhNodes;
+  std::vector<LeafTri> leafTris;
+  std::vector<u4> triVerts;
+  std::vector<int32_t> triLight;
+  std::vector<f4> vPos, vNormal, vTangent;
+  std::vector<f2> vUV;
+  std::vector<MeshDev> meshes;
+  std::vector<NodeDev> nodes;
+  std::vector<MaterialDev> materials;
+  std::vector<TexDev> textures;
+  std::vector<uint8_t> texU8;
+  std::vector<float> texF32;
+  std::vector<LightDev> lights;
+  std::vector<EnvDev> envs;
+  std::vector<float> envData;
+  std::vector<uint32_t> infiniteLights, areaLights;
+  std::vector<float> areaPowerCdf;
+  std::vector<float> lut;                          // LutDev layout (incl. Sobol matrix bits)
+  std::vector<std::vector<uint32_t>> bvhIndices;   // per mesh, for yart_hip_bvh_copy
+  float totalPower = 0.0f;
+  uint32_t maxNodeDepth = 0;
+  uint32_t nLights = 0, nInfinite = 0, nArea = 0, nMaterials = 0;   // real counts (the vectors are padded)
+
+  SceneDev view() const {
+    SceneDev s{};
+    s.bvhNodes = bvhNodes.data(); s.leafTris = leafTris.data(); s.triVerts = triVerts.data();
+    s.triLight = triLight.data(); s.vPos = vPos.data(); s.vNormal = vNormal.data();
+    s.vTangent = vTangent.data(); s.vUV = vUV.data(); s.meshes = meshes.data(); s.nodes = nodes.data();
+    s.materials = materials.data(); s.textures = textures.data(); s.texU8 = texU8.data();
+    s.texF32 = texF32.data(); s.lights = lights.data(); s.envs = envs.data(); s.envData = envData.data();
+    s.infiniteLights = infiniteLights.data(); s.areaLights = areaLights.data();
+    s.areaPowerCdf = areaPowerCdf.data(); s.lut = lut.data();
+    s.nNodes = uint32_t(nodes.size()); s.nLights = nLights;
+    s.nInfinite = nInfinite; s.nArea = nArea;
+    s.totalPower = totalPower;
+    return s;
+  }
+};
+
+// LUT tables (bsdf/luts.cpp data, dumped by oracle/_ref into yart_amd/data/ggx_luts.bin
+// and embedded at build time; see yart_amd/data/README.md)
+const float* embeddedLutTables();      // 14112 floats, LutDev layout
+
+inline void require(bool ok, const char* what) {
+  if (!ok) throw std::invalid_argument(what);
+}
+
+// float4x4::rotation(angle, axis_z) -> float3x3 (mat.hpp:52-74, parametric.cpp:52-53)
+inline void rotationZ3x3(float angle, float* m9) {
+  const float a = angle;
+  const float c = std::cos(a);
+  const float s = std::sin(a);
+  const float ax[3] = {0.0f, 0.0f, 1.0f};
+  const float len = std::sqrt((ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2]);
+  const float n[3] = {ax[0] / len, ax[1] / len, ax[2] / len};
+  const float k = float(1.0 - double(c));          // "(1.0 - c) * nAxis": double subtract, then T(lhs)
+  const float t[3] = {n[0] * k, n[1] * k, n[2] * k};
+  m9[0] = c + t[0] * n[0];          m9[1] = t[1] * n[0] - s * n[2];   m9[2] = t[2] * n[0] + s * n[1];
+  m9[3] = t[0] * n[1] + s * n[2];   m9[4] = c + t[1] * n[1];          m9[5] = t[2] * n[1] - s * n[0];
+  m9[6] = t[0] * n[2] - s * n[1];   m9[7] = t[1] * n[2] + s * n[0];   m9[8] = c + t[2] * n[2];
+}
+
+inline float triangleAreaHost(f3 p0, f3 p1, f3 p2) {       // primitives.hpp:24-32
+  return length(cross(p1 - p0, p2 - p0)) * 0.5f;
+}
+
+inline HostImage buildHostImage(const YartSceneDesc& d) {
+  require(d.n_nodes >= 1 && d.nodes, "scene needs a root node");
+  require(d.n_materials == 0 || d.materials, "materials pointer is null");
+  require(d.n_meshes == 0 || d.meshes, "meshes pointer is null");
+  HostImage im;
+
+  // ---- textures -------------------------------------------------------------
+  for (uint32_t i = 0; i < d.n_textures; i++) {
+    const YartTextureDesc& t = d.textures[i];
+    require(t.data && t.width >= 2 && t.height >= 2 && t.channels >= 1 && t.channels <= 4,
+            "texture: needs data, >= 2x2 texels, 1-4 channels");
+    TexDev td{};
+    td.width = t.width; td.height = t.height; td.channels = t.channels; td.type = t.type;
+    td.isFloat = t.is_float ? 1u : 0u;
+    size_t n = size_t(t.width) * t.height * t.channels;
+    if (t.is_float) {
+      td.offset = uint32_t(im.texF32.size());
+      const float* p = static_cast<const float*>(t.data);
+      im.texF32.insert(im.texF32.end(), p, p + n);
+    } else {
+      td.offset = uint32_t(im.texU8.size());
+      const uint8_t* p = static_cast<const uint8_t*>(t.data);
+      im.texU8.insert(im.texU8.end(), p, p + n);
+      while (im.texU8.size() % 4) im.texU8.push_back(0);
+    }
+    im.textures.push_back(td);
+  }
+  auto texOk = [&](int32_t t, uint32_t ch, bool isFloat) {
+    return t < 0 || (uint32_t(t) < d.n_textures && d.textures[t].channels == ch &&
+                     (d.textures[t].is_float != 0) == isFloat);
+  };
+
+  // ---- materials (parametric.cpp:11-68) ---------------------------------------
+  for (uint32_t i = 0; i < d.n_materials; i++) {
+    const YartMaterialDesc& m = d.materials[i];
+    require(texOk(m.tex_base, 4, false) && texOk(m.tex_mr, 2, false) && texOk(m.tex_transmission, 1, false) &&
+            texOk(m.tex_normal, 3, false) && texOk(m.tex_clearcoat, 1, false) && texOk(m.tex_emission, 3, false),
+            "material: texture index / channel count mismatch");
+    MaterialDev md{};
+    md.base = mk3(m.base[0], m.base[1], m.base[2]);
+    md.emission = mk3(m.emission[0], m.emission[1], m.emission[2]);
+    md.cTrans = m.transmission; md.cMetallic = m.metallic; md.ior = m.ior; md.roughness = m.roughness;
+    md.anisotropic = m.anisotropic; md.clearcoat = m.clearcoat; md.clearcoatRoughness = m.clearcoat_roughness;
+    md.volumeColor = mk3(m.volume_color[0], m.volume_color[1], m.volume_color[2]);
+    md.volumeDensity = m.volume_density;
+    md.texBase = m.tex_base; md.texMR = m.tex_mr; md.texTransmission = m.tex_transmission;
+    md.texNormal = m.tex_normal; md.texClearcoat = m.tex_clearcoat; md.texEmission = m.tex_emission;
+    rotationZ3x3(-m.aniso_rotation, md.localRot);
+    rotationZ3x3(m.aniso_rotation, md.invRot);
+    uint32_t flags = 0;
+    if (m.thin_transmission) flags |= MAT_THIN;
+    if (m.tex_base >= 0) {                                  // parametric.cpp:61-63
+      const YartTextureDesc& t = d.textures[m.tex_base];
+      const uint8_t* p = static_cast<const uint8_t*>(t.data);
+      size_t n = size_t(t.width) * t.height * 4;
+      for (size_t k = 3; k < n; k += 4) if (p[k] < 255) { flags |= MAT_HAS_ALPHA; break; }
+    }
+    if (length2(md.emission) > 0.0f) flags |= MAT_HAS_EMISSION;          // :67
+    if (m.thin_transmission && m.transmission > 0.0f) flags |= MAT_TRANSPARENT;   // :80-82
+    md.flags = flags;
+    im.materials.push_back(md);
+  }
+
+  // ---- meshes: BVH + leaf records (mesh.hpp:27-61, bvh.hpp) --------------------
+  for (uint32_t mi = 0; mi < d.n_meshes; mi++) {
+    const YartMeshDesc& m = d.meshes[mi];
+    require(m.positions && m.normals && m.tangents && m.uvs && m.faces && m.n_faces > 0 && m.n_vertices > 0,
+            "mesh: null array or empty mesh");
+    for (uint32_t f = 0; f < m.n_faces; f++) {
+      require(m.faces[4 * f] < m.n_vertices && m.faces[4 * f + 1] < m.n_vertices &&
+              m.faces[4 * f + 2] < m.n_vertices, "mesh: vertex index out of range");
+      require(m.faces[4 * f + 3] < d.n_materials, "mesh: material index out of range");
+    }
+    MeshDev md{};
+    // children live at (left, left+1) with left odd (root = 0, pairs allocated after it),
+    // so an odd mesh base puts every sibling pair on a 64-byte boundary
+    if (im.bvhNodes.size() % 2 == 0) im.bvhNodes.push_back(BvhNode{});
+    md.nodeOffset = uint32_t(im.bvhNodes.size());
+    md.leafOffset = uint32_t(im.leafTris.size());
+    md.triOffset = uint32_t(im.triVerts.size());
+    md.vertOffset = uint32_t(im.vPos.size());
+    md.nTris = m.n_faces; md.nVerts = m.n_vertices;
+
+    SahBvhBuilder b;
+    b.build(m.positions, m.faces, 4, m.n_faces);
+    md.nNodes = uint32_t(b.nodes.size());
+    im.bvhNodes.insert(im.bvhNodes.end(), b.nodes.begin(), b.nodes.end());
+    for (uint32_t k = 0; k < m.n_faces; k++) {
+      uint32_t t = b.indices[k];
+      const float* p0 = m.positions + size_t(m.faces[4 * t]) * 3;
+      const float* p1 = m.positions + size_t(m.faces[4 * t + 1]) * 3;
+      const float* p2 = m.positions + size_t(m.faces[4 * t + 2]) * 3;
+      LeafTri lt{};
+      for (int c = 0; c < 3; c++) { lt.p0[c] = p0[c]; lt.e1[c] = p1[c] - p0[c]; lt.e2[c] = p2[c] - p0[c]; }
+      lt.triIdx = t;
+      lt.material = m.faces[4 * t + 3];
+      lt.matFlags = im.materials[lt.material].flags & (MAT_HAS_ALPHA | MAT_TRANSPARENT);
+      im.leafTris.push_back(lt);
+    }
+    for (uint32_t f = 0; f < m.n_faces; f++) {
+      u4 tv; tv.x = m.faces[4 * f]; tv.y = m.faces[4 * f + 1]; tv.z = m.faces[4 * f + 2]; tv.w = m.faces[4 * f + 3];
+      im.triVerts.push_back(tv);
+      im.triLight.push_back(m.face_light ? m.face_light[f] : -1);
+    }
+    for (uint32_t v = 0; v < m.n_vertices; v++) {
+      f4 p; p.x = m.positions[3 * v]; p.y = m.positions[3 * v + 1]; p.z = m.positions[3 * v + 2]; p.w = 0;
+      f4 n; n.x = m.normals[3 * v]; n.y = m.normals[3 * v + 1]; n.z = m.normals[3 * v + 2]; n.w = 0;
+      f4 t; t.x = m.tangents[4 * v]; t.y = m.tangents[4 * v + 1]; t.z = m.tangents[4 * v + 2]; t.w = m.tangents[4 * v + 3];
+      im.vPos.push_back(p); im.vNormal.push_back(n); im.vTangent.push_back(t);
+      im.vUV.push_back(mk2(m.uvs[2 * v], m.uvs[2 * v + 1]));
+    }
+    im.meshes.push_back(md);
+    im.bvhIndices.push_back(std::move(b.indices));
+  }
+
+  // ---- scene graph (scene.hpp:11-64): pre-order with skip links, children-inclusive bounds
+  const uint32_t nn = d.n_nodes;
+  im.nodes.resize(nn);
+  std::vector<Bounds3> nb(nn);
+  for (uint32_t i = 0; i < nn; i++) {
+    const YartNodeDesc& n = d.nodes[i];
+    require(i == 0 ? n.parent < 0 : (n.parent >= 0 && uint32_t(n.parent) < i), "nodes must be in pre-order");
+    require(n.mesh < int32_t(d.n_meshes), "node: mesh index out of range");
+    NodeDev& nd = im.nodes[i];
+    std::memcpy(nd.xf.fwd, n.fwd, 64); std::memcpy(nd.xf.inv, n.inv, 64);
+    nd.mesh = n.mesh; nd.parent = n.parent;
+    nd.depth = i == 0 ? 0 : im.nodes[n.parent].depth + 1;
+    require(nd.depth < kMaxNodeDepth, "scene graph deeper than 8 levels");
+    if (nd.depth > im.maxNodeDepth) im.maxNodeDepth = nd.depth;
+    if (n.mesh >= 0) {                                          // Node(Mesh*), scene.hpp:17-22
+      const YartMeshDesc& m = d.meshes[n.mesh];
+      for (uint32_t v = 0; v < m.n_vertices; v++) nb[i].expand(m.positions + size_t(v) * 3);
+    }
+  }
+  for (uint32_t i = nn; i-- > 1;) {                             // appendChild bottom-up, scene.hpp:48-52
+    const NodeDev& c = im.nodes[i];
+    const Bounds3& b = nb[i];
+    float corners[8][3];
+    int k = 0;                                                  // transform.hpp:75-90 corner order
+    for (int xi = 0; xi < 2; xi++) for (int yi = 0; yi < 2; yi++) for (int zi = 0; zi < 2; zi++) {
+      f3 p = mulPoint(c.xf.fwd, mk3(xi ? b.mx[0] : b.mn[0], yi ? b.mx[1] : b.mn[1], zi ? b.mx[2] : b.mn[2]));
+      corners[k][0] = p.x; corners[k][1] = p.y; corners[k][2] = p.z; k++;
+    }
+    const float* ptr[8];
+    for (int q = 0; q < 8; q++) ptr[q] = corners[q];
+    nb[c.parent].join(boundsFromPoints(ptr, 8));
+  }
+  // NB: children are joined in reverse order here; min/max folding is order independent.
+  for (uint32_t i = 0; i < nn; i++) {
+    NodeDev& nd = im.nodes[i];
+    for (int c = 0; c < 3; c++) { nd.bmin[c] = nb[i].mn[c]; nd.bmax[c] = nb[i].mx[c]; }
+    uint32_t j = i + 1;
+    while (j < nn && im.nodes[j].depth > nd.depth) j++;
+    nd.skip = j;
+  }
+
+  // ---- lights (light.cpp, light-sampler.cpp:32-50) ------------------------------
+  for (uint32_t i = 0; i < d.n_lights; i++) {
+    const YartLightDesc& l = d.lights[i];
+    LightDev ld{};
+    ld.type = l.type; ld.mesh = l.mesh; ld.tri = l.tri; ld.twoSided = l.two_sided;
+    ld.emission = mk3(l.emission[0], l.emission[1], l.emission[2]);
+    ld.radius = l.radius; ld.texture = l.texture;
+    std::memcpy(ld.xf.fwd, l.fwd, 64); std::memcpy(ld.xf.inv, l.inv, 64);
+    if (l.type == LIGHT_AREA) {
+      require(l.mesh >= 0 && uint32_t(l.mesh) < d.n_meshes && l.tri < d.meshes[l.mesh].n_faces,
+              "area light: mesh / triangle out of range");
+      const YartMeshDesc& m = d.meshes[l.mesh];
+      auto P = [&](uint32_t v) { return mk3(m.positions[3 * v], m.positions[3 * v + 1], m.positions[3 * v + 2]); };
+      f3 t0 = mulPoint(ld.xf.fwd, P(m.faces[4 * l.tri]));
+      f3 t1 = mulPoint(ld.xf.fwd, P(m.faces[4 * l.tri + 1]));
+      f3 t2 = mulPoint(ld.xf.fwd, P(m.faces[4 * l.tri + 2]));
+      ld.area = triangleAreaHost(t0, t1, t2);                                   // light.cpp:26-33
+      ld.power = length(ld.emission) * ld.area * kPi * (l.two_sided ? 2.0f : 1.0f);   // :36-38
+      im.areaLights.push_back(i);
+      im.areaPowerCdf.push_back(im.totalPower + ld.power);                      // light-sampler.cpp:46-47
+      im.totalPower += ld.power;
+    } else if (l.type == LIGHT_UNIFORM_INF) {
+      ld.power = 4.0f * kPi * kPi * l.radius * l.radius * length(ld.emission);   // light.cpp:98-103
+      im.infiniteLights.push_back(i);
+    } else if (l.type == LIGHT_IMAGE_INF) {
+      require(l.texture >= 0 && uint32_t(l.texture) < d.n_textures && d.textures[l.texture].is_float &&
+              d.textures[l.texture].channels == 3, "image light: needs a float RGB texture");
+      const YartTextureDesc& t = d.textures[l.texture];
+      const float* px = static_cast<const float*>(t.data);
+      const uint32_t w = t.width, h = t.height;                 // full (0,0)-(1,1) bounds: x0=y0=0
+      EnvDev e{};
+      e.w = w; e.h = h;
+      e.funcOffset = uint32_t(im.envData.size());
+      std::vector<float> func(size_t(w) * h);
+      f3 Lavg = mk3(0);
+      for (uint32_t y = 0; y < h; y++) {                        // light.cpp:156-170
+        float v = (float(y) + 0.5f) / float(h);
+        float z = 1.0f - v * 2.0f;
+        float sinTheta = std::sqrt(1.0f - z * z);
+        for (uint32_t x = 0; x < w; x++) {
+          const float* s = px + (size_t(x) + size_t(y) * w) * 3;
+          float value = (((0.0f + s[0]) + s[1]) + s[2]) / 3.0f;
+          func[size_t(y) * w + x] = std::fabs(value * sinTheta);    // PiecewiseConstant1D takes |f|
+          Lavg += mk3(s[0], s[1], s[2]);
+        }
+      }
+      Lavg /= float(w * h);
+      im.envData.insert(im.envData.end(), func.begin(), func.end());
+      e.cdfOffset = uint32_t(im.envData.size());
+      std::vector<float> rowInt(h);
+      for (uint32_t y = 0; y < h; y++) {                        // sampling.hpp:122-143
+        std::vector<float> cdf(w + 1);
+        cdf[0] = 0.0f;
+        for (uint32_t k = 1; k < w + 1; k++) cdf[k] = cdf[k - 1] + func[size_t(y) * w + k - 1] * (1.0f - 0.0f) / float(w);
+        float integral = cdf[w];
+        if (integral == 0.0f) for (uint32_t k = 1; k < w + 1; k++) cdf[k] = float(k) / float(w);
+        else for (uint32_t k = 1; k < w + 1; k++) cdf[k] /= integral;
+        rowInt[y] = integral;
+        im.envData.insert(im.envData.end(), cdf.begin(), cdf.end());
+      }
+      e.rowIntOffset = uint32_t(im.envData.size());
+      for (uint32_t y = 0; y < h; y++) im.envData.push_back(std::fabs(rowInt[y]));
+      e.margCdfOffset = uint32_t(im.envData.size());
+      {
+        std::vector<float> cdf(h + 1);
+        cdf[0] = 0.0f;
+        for (uint32_t k = 1; k < h + 1; k++) cdf[k] = cdf[k - 1] + std::fabs(rowInt[k - 1]) * (1.0f - 0.0f) / float(h);
+        float integral = cdf[h];
+        if (integral == 0.0f) for (uint32_t k = 1; k < h + 1; k++) cdf[k] = float(k) / float(h);
+        else for (uint32_t k = 1; k < h + 1; k++) cdf[k] /= integral;
+        e.margIntegral = integral;
+        im.envData.insert(im.envData.end(), cdf.begin(), cdf.end());
+      }
+      float phi0 = 0.0f * 2.0f * kPi, phi1 = 1.0f * 2.0f * kPi;              // light.cpp:192-196
+      float theta0 = 0.0f * kPi, theta1 = 1.0f * kPi;
+      e.surfaceArea = (phi1 - phi0) * (std::cos(theta0) - std::cos(theta1));
+      ld.power = e.surfaceArea * kPi * l.radius * l.radius * (((0.0f + Lavg.x) + Lavg.y) + Lavg.z) / 3.0f;   // :206-209
+      ld.envOffset = uint32_t(im.envs.size());
+      im.envs.push_back(e);
+      im.infiniteLights.push_back(i);
+    } else {
+      require(false, "light: unknown type");
+    }
+    im.lights.push_back(ld);
+  }
+  // hit.lightIdx (per-mesh numbering) is used as a global light index by the reference
+  // (mis-integrator.cpp:65): validate it stays in range.
+  for (int32_t li : im.triLight) require(li < int32_t(im.lights.size()), "face_light index out of range");
+
+  // ---- LUTs + Sobol dimension-1 matrix ------------------------------------------
+  im.lut.assign(embeddedLutTables(), embeddedLutTables() + LutDev::sobol);
+  im.lut.resize(LutDev::total);
+  for (uint32_t k = 0; k < 52; k++) {
+    uint32_t bits = sobolDim1Column(k);
+    std::memcpy(&im.lut[LutDev::sobol + k], &bits, 4);
+  }
+  im.nLights = uint32_t(im.lights.size()); im.nInfinite = uint32_t(im.infiniteLights.size());
+  im.nArea = uint32_t(im.areaLights.size()); im.nMaterials = uint32_t(im.materials.size());
+  // never hand the kernels a null pointer for an empty table
+  if (im.texU8.empty()) im.texU8.resize(4);
+  if (im.texF32.empty()) im.texF32.resize(1);
+  if (im.textures.empty()) im.textures.push_back(TexDev{});
+  if (im.lights.empty()) im.lights.push_back(LightDev{});
+  if (im.envs.empty()) im.envs.push_back(EnvDev{});
+  if (im.envData.empty()) im.envData.resize(1);
+  if (im.infiniteLights.empty()) im.infiniteLights.push_back(0);
+  if (im.areaLights.empty()) im.areaLights.push_back(0);
+  if (im.areaPowerCdf.empty()) im.areaPowerCdf.push_back(0.0f);
+  if (im.materials.empty()) im.materials.push_back(MaterialDev{});
+  return im;
+}
+
+// Camera::calcDerivedProperties (camera.hpp:25-59) after moveAndLookAt (:123-130)
+inline CameraDev makeCamera(const YartCameraDesc& c) {
+  require(c.width > 0 && c.height > 0 && c.focal_length > 0, "camera: bad image size / focal length");
+  CameraDev cd{};
+  const float aspect = float(c.width) / float(c.height);
+  const f3 position = mk3(c.position[0], c.position[1], c.position[2]);
+  const f3 forward = mk3(c.target[0], c.target[1], c.target[2]) - position;
+  f3 up = mk3(c.up[0], c.up[1], c.up[2]);
+  if (length2(up) == 0.0f) up = mk3(0, 1, 0);
+  float sensorAspect = c.sensor[0] / c.sensor[1];
+  float croppedSensorHeight = c.sensor[0] / ymax(sensorAspect, aspect);
+  float focusDistance = length(forward);
+  float vh = focusDistance * croppedSensorHeight / c.focal_length;
+  float vw = vh * aspect;
+  up = normalized(up);
+  f3 w = normalized(-forward);
+  f3 u = cross(up, w);
+  f3 v = cross(w, u);
+  Frame fr = frameFromNormalTangent(w, u, 1.0f);
+  f3 viewportU = u * vw;
+  f3 viewportV = (-v) * vh;
+  f3 viewportTopLeft = (position - w * focusDistance) - (viewportU + viewportV) * 0.5f;
+  cd.pixelDeltaU = viewportU / float(c.width);
+  cd.pixelDeltaV = viewportV / float(c.height);
+  cd.topLeftPixel = viewportTopLeft + (cd.pixelDeltaU + cd.pixelDeltaV) * 0.5f;
+  cd.apertureRadius = c.f_number ? (c.focal_length / 2000.0f) / c.f_number : 0.0f;
+  cd.apertureSides = c.aperture_sides;
+  cd.position = position;
+  cd.frameX = fr.x; cd.frameY = fr.y; cd.frameZ = fr.z;
+  cd.exposureScale = std::exp2(c.exposure);                   // integrator.cpp:23
+  return cd;
+}
+
+}  // namespace yart_hip

@@ -1,0 +1,150 @@
+// sampler.hpp — ZSobol sampler with FastOwen scrambling (integer path; bit-exact).
+//
+// Restates reference core/sampler.hpp:72-174 (SobolSampler), core/scrambler.hpp:53-69
+// (FastOwenScrambler), core/rng.hpp:25-100 (murmurHash64A on a 4-byte key, mixBits)
+// and math/math.hpp:102-134 (bit reversal, Morton code) as a register-resident
+// state machine: {dim, mortonIndex} per path, {log2spp, nBase4Digits} per render.
+#pragma once
+#include "ymath.hpp"
+
+namespace yart_hip {
+
+struct SamplerConfig {
+  uint32_t log2spp;       // log2Int(float(spp)), math_base.hpp:156-160
+  uint32_t nBase4Digits;  // log2Int(roundUpPow2(tile)) + (log2spp+1)/2, sampler.hpp:74-82
+};
+
+// math_base.hpp:156-160 — rounds to nearest in log space (48 -> 6)
+inline int32_t log2IntHost(float v) {
+  if (v < 1) return -log2IntHost(1 / v);
+  uint32_t b; std::memcpy(&b, &v, 4);
+  const uint32_t midsignif = 0x3504f3u;
+  return int32_t(b >> 23) - 127 + (((b & 0x7fffffu) >= midsignif) ? 1 : 0);
+}
+inline int32_t roundUpPow2Host(int32_t v) {   // math_base.hpp:162-170
+  v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+  return v + 1;
+}
+inline SamplerConfig makeSamplerConfig(uint32_t spp, uint32_t tileSize) {
+  SamplerConfig c;
+  c.log2spp = uint32_t(log2IntHost(float(spp)));
+  // maxComponent(uint2{tile,tile}) starts from numeric_limits<unsigned>::min() = 0
+  uint32_t res = uint32_t(roundUpPow2Host(int32_t(tileSize)));
+  uint32_t log4spp = (c.log2spp + 1) / 2;
+  c.nBase4Digits = uint32_t(log2IntHost(float(res))) + log4spp;
+  return c;
+}
+
+YART_HD uint64_t mixBits(uint64_t v) {     // rng.hpp:93-100
+  v ^= (v >> 31);
+  v *= 0x7fb5d329728ea185ull;
+  v ^= (v >> 27);
+  v *= 0x81dadef4bc2dd44dull;
+  v ^= (v >> 33);
+  return v;
+}
+
+// hash(uint32_t) = murmurHash64A over the 4 key bytes, seed 0 (rng.hpp:25-91):
+// len=4 -> no 8-byte blocks; tail switch cases 4..1 xor the little-endian value.
+YART_HD uint64_t hashDim(uint32_t dim) {
+  const uint64_t m = 0xc6a4a7935bd1e995ull;
+  uint64_t h = 0ull ^ (4ull * m);
+  h ^= uint64_t(dim);
+  h *= m;
+  h ^= h >> 47;
+  h *= m;
+  h ^= h >> 47;
+  return h;
+}
+
+YART_HD uint32_t fastOwen(uint32_t v, uint32_t seed) {   // scrambler.hpp:57-65
+  v = reverseBits32(v);
+  v ^= v * 0x3d20adeau;
+  v += seed;
+  v *= (seed >> 16) | 1u;
+  v ^= v * 0x05526c56u;
+  v ^= v * 0x53a22864u;
+  return reverseBits32(v);
+}
+
+// Generator matrix of Sobol' dimension 1 as the reference's table holds it
+// (sobol.tables entries 52..103): column k<32 is row k of Pascal's triangle mod 2,
+// v[k] = v[k-1] ^ (v[k-1] >> 1), v[0] = 1<<31; the 52-column table repeats the
+// first 20 columns for k = 32..51. Checked against the reference table in
+// tests/test_oracle_kat.py (dump: oracle/_ref/yart_ref luts).
+YART_HD uint32_t sobolDim1Column(uint32_t k) {
+  // closed form: bit (31-j) of column k is C(k, j) mod 2 = ((k & j) == j) (Lucas)
+  k &= 31u;   // columns 32..51 repeat 0..19 in the reference table
+  uint32_t v = 0;
+  for (uint32_t j = 0; j <= k; j++) v |= (((k & j) == j) ? 1u : 0u) << (31u - j);
+  return v;
+}
+
+struct Sampler {
+  uint64_t morton;
+  uint32_t dim;
+};
+
+// permutations[24][4] of sampler.hpp:115-140, 2 bits per entry, 8 bits per row
+YART_HD uint32_t permutationRow(uint32_t p) {
+  // rows packed little-endian: digit d -> (row >> (2*d)) & 3
+  const uint8_t rows[24] = {
+    0xE4, 0xB4, 0xD8, 0x78, 0x6C, 0x9C, 0xE1, 0xB1, 0xC9, 0x39, 0x2D, 0x8D,
+    0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93};
+  return rows[p];
+}
+
+YART_HD void startPixelSample(Sampler& s, const SamplerConfig& c, uint32_t px, uint32_t py,
+                              uint32_t sample) {         // sampler.hpp:84-87
+  s.dim = 0;
+  s.morton = (encodeMorton2(px, py) << c.log2spp) | uint64_t(sample);
+}
+
+YART_HD uint64_t getSampleIndex(const Sampler& s, const SamplerConfig& c) {   // sampler.hpp:155-173
+  uint64_t index = 0;
+  const bool pow2Samples = c.log2spp & 1u;
+  const int lastDigit = pow2Samples ? 1 : 0;
+  const uint64_t dimMix = uint64_t(0x55555555u * s.dim);      // 32-bit wrapping multiply
+  for (int i = int(c.nBase4Digits) - 1; i >= lastDigit; i--) {
+    uint32_t digitShift = uint32_t(2 * i - lastDigit);
+    uint32_t digit = uint32_t(s.morton >> digitShift) & 3u;
+    uint64_t higherDigits = s.morton >> (digitShift + 2);
+    uint32_t p = uint32_t((mixBits(higherDigits ^ dimMix) >> 24) % 24ull);
+    digit = (permutationRow(p) >> (2u * digit)) & 3u;
+    index |= uint64_t(digit) << digitShift;
+  }
+  if (pow2Samples) {
+    uint32_t digit = uint32_t(s.morton & 1ull);
+    index |= uint64_t(digit ^ uint32_t(mixBits((s.morton >> 1) ^ dimMix) & 1ull));
+  }
+  return index;
+}
+
+YART_HD float sobolToFloat(uint32_t v) {                  // sampler.hpp:152
+  return stdmin(float(v) * 0x1p-32f, kOneMinusEpsilon);
+}
+
+YART_HD float sobolDim0(uint64_t idx, uint32_t seed) {    // sampler.hpp:144-145
+  return sobolToFloat(fastOwen(reverseBits32(uint32_t(idx)), seed));
+}
+YART_HD float sobolDim1(uint64_t idx, uint32_t seed, const uint32_t* __restrict__ matrix52) {
+  uint32_t v = 0;
+  uint64_t d = idx;
+  for (uint32_t i = 0; d != 0; d >>= 1, i++) v ^= uint32_t(d & 1ull) * matrix52[i];   // :147-149
+  return sobolToFloat(fastOwen(v, seed));
+}
+
+YART_HD float get1D(Sampler& s, const SamplerConfig& c) {           // sampler.hpp:89-94
+  uint64_t idx = getSampleIndex(s, c);
+  s.dim++;
+  uint32_t h = uint32_t(hashDim(s.dim));
+  return sobolDim0(idx, h);
+}
+YART_HD f2 get2D(Sampler& s, const SamplerConfig& c, const uint32_t* __restrict__ matrix52) {   // :96-107
+  uint64_t idx = getSampleIndex(s, c);
+  s.dim += 2;
+  uint64_t hb = hashDim(s.dim);
+  return mk2(sobolDim0(idx, uint32_t(hb)), sobolDim1(idx, uint32_t(hb >> 32), matrix52));
+}
+
+}  // namespace yart_hip

@@ -1,0 +1,98 @@
+// scene_file.hpp — reader of the .yscn scene container for the product library
+// (yart_hip_scene_load). The container stands where the reference's glTF loader
+// output stands (src/gltf/gltf.cpp:319-358); layout documented in oracle/yscn.hpp
+// and written by yart_amd/yscn.py.
+#pragma once
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/yart_hip.h"
+
+namespace yart_hip {
+
+struct LoadedScene {
+  std::vector<std::vector<uint8_t>> blobs;      // owns every array the descriptors point into
+  std::vector<YartTextureDesc> textures;
+  std::vector<YartMaterialDesc> materials;
+  std::vector<YartMeshDesc> meshes;
+  std::vector<YartNodeDesc> nodes;
+  std::vector<YartLightDesc> lights;
+  YartSceneDesc desc{};
+};
+
+inline std::unique_ptr<LoadedScene> loadSceneFile(const std::string& path) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("cannot open scene file " + path);
+  std::vector<uint8_t> file;
+  std::fseek(f, 0, SEEK_END);
+  long sz = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  file.resize(size_t(sz));
+  size_t got = std::fread(file.data(), 1, file.size(), f);
+  std::fclose(f);
+  if (got != file.size()) throw std::runtime_error("short read on " + path);
+
+  size_t pos = 0;
+  auto need = [&](size_t n) { if (pos + n > file.size()) throw std::runtime_error("truncated scene file"); };
+  auto u32 = [&]() { need(4); uint32_t v; std::memcpy(&v, &file[pos], 4); pos += 4; return v; };
+  auto s = std::make_unique<LoadedScene>();
+  auto blob = [&](size_t bytes) -> const void* {
+    need(bytes);
+    s->blobs.emplace_back(file.begin() + long(pos), file.begin() + long(pos + bytes));
+    pos += bytes + (4 - bytes % 4) % 4;
+    return s->blobs.back().data();
+  };
+  need(8);
+  if (std::memcmp(file.data(), "YSCN0001", 8) != 0) throw std::runtime_error("not a .yscn file");
+  pos = 8;
+  uint32_t nt = u32(), nm = u32(), nme = u32(), nn = u32(), nl = u32();
+  u32(); u32(); u32();
+  for (uint32_t i = 0; i < nt; i++) {
+    YartTextureDesc t{};
+    t.width = u32(); t.height = u32(); t.channels = u32(); t.is_float = u32(); t.type = u32();
+    t.data = blob(size_t(t.width) * t.height * t.channels * (t.is_float ? 4 : 1));
+    s->textures.push_back(t);
+  }
+  static_assert(sizeof(YartMaterialDesc) == 26 * 4, "YartMaterialDesc must match the file record");
+  for (uint32_t i = 0; i < nm; i++) {
+    need(sizeof(YartMaterialDesc));
+    YartMaterialDesc m;
+    std::memcpy(&m, &file[pos], sizeof(m)); pos += sizeof(m);
+    s->materials.push_back(m);
+  }
+  for (uint32_t i = 0; i < nme; i++) {
+    YartMeshDesc m{};
+    m.n_vertices = u32(); m.n_faces = u32();
+    m.positions = static_cast<const float*>(blob(size_t(m.n_vertices) * 12));
+    m.normals = static_cast<const float*>(blob(size_t(m.n_vertices) * 12));
+    m.tangents = static_cast<const float*>(blob(size_t(m.n_vertices) * 16));
+    m.uvs = static_cast<const float*>(blob(size_t(m.n_vertices) * 8));
+    m.faces = static_cast<const uint32_t*>(blob(size_t(m.n_faces) * 16));
+    m.face_light = static_cast<const int32_t*>(blob(size_t(m.n_faces) * 4));
+    s->meshes.push_back(m);
+  }
+  static_assert(sizeof(YartNodeDesc) == 34 * 4 && sizeof(YartLightDesc) == 41 * 4, "record layouts");
+  for (uint32_t i = 0; i < nn; i++) {
+    need(sizeof(YartNodeDesc));
+    YartNodeDesc n;
+    std::memcpy(&n, &file[pos], sizeof(n)); pos += sizeof(n);
+    s->nodes.push_back(n);
+  }
+  for (uint32_t i = 0; i < nl; i++) {
+    need(sizeof(YartLightDesc));
+    YartLightDesc l;
+    std::memcpy(&l, &file[pos], sizeof(l)); pos += sizeof(l);
+    s->lights.push_back(l);
+  }
+  s->desc.n_textures = nt; s->desc.n_materials = nm; s->desc.n_meshes = nme;
+  s->desc.n_nodes = nn; s->desc.n_lights = nl;
+  s->desc.textures = s->textures.data(); s->desc.materials = s->materials.data();
+  s->desc.meshes = s->meshes.data(); s->desc.nodes = s->nodes.data(); s->desc.lights = s->lights.data();
+  return s;
+}
+
+}  // namespace yart_hip

@@ -1,0 +1,149 @@
+// scene_types.hpp — the flattened, pointer-free scene image the kernels read.
+//
+// The reference holds the scene as a pointer graph (core/scene.hpp:11-169,
+// core/mesh.hpp:15-128, core/bvh.hpp:21-33, core/light.hpp, bsdf/parametric.hpp).
+// For the GPU everything becomes index-addressed arrays in HBM:
+//
+//   bvhNodes   32-byte nodes exactly as the reference builds them (bounds, left|first,
+//              span); the two children of an inner node are adjacent, so one 64-byte
+//              aligned fetch (nodes[left], nodes[left+1]) serves an inner visit.
+//   leafTris   48-byte records in BVH leaf order (the reference chases
+//              m_indices -> Triangle -> 3 vertices, 52 B over 3 dependent loads):
+//              {p0, triIdx | e1 = p1-p0, material flags | e2 = p2-p0, material}.
+//   triVerts / triLight / vertex arrays   per original triangle / vertex, read once
+//              per accepted hit by the shading code.
+//   nodes      scene-graph nodes in pre-order with a skip link, so that the
+//              reference's recursive testNode becomes a linear walk.
+#pragma once
+#include "ymath.hpp"
+
+namespace yart_hip {
+
+constexpr uint32_t kMaxNodeDepth = 8;   // scene-graph nesting the node walk supports
+
+enum : uint32_t { TEX_LINEAR = 0, TEX_SRGB = 1, TEX_NONCOLOR = 2 };
+enum : uint32_t { LIGHT_AREA = 0, LIGHT_UNIFORM_INF = 1, LIGHT_IMAGE_INF = 2 };
+enum : uint32_t {
+  MAT_THIN = 1u, MAT_HAS_ALPHA = 2u, MAT_HAS_EMISSION = 4u, MAT_TRANSPARENT = 8u
+};
+
+struct TexDev {            // core/texture.hpp:21-49
+  uint32_t offset;         // element offset into texU8 (bytes) or texF32 (floats)
+  uint32_t width, height, channels;
+  uint32_t type;           // TEX_*
+  uint32_t isFloat;
+};
+
+struct MaterialDev {       // bsdf/parametric.hpp:52-77
+  f3 base; float cTrans;
+  f3 emission; float cMetallic;
+  float ior, roughness, anisotropic, clearcoat;
+  float clearcoatRoughness; uint32_t flags; float volumeDensity; int32_t texBase;
+  f3 volumeColor; int32_t texMR;
+  int32_t texTransmission, texNormal, texClearcoat, texEmission;
+  float localRot[9];       // float3x3(rotation(-anisoRotation, z)), parametric.cpp:52
+  float invRot[9];         // float3x3(rotation(+anisoRotation, z)), parametric.cpp:53
+  float pad[2];
+};
+
+struct BvhNode {           // core/bvh.hpp:21-33 (32 bytes)
+  float bmin[3];
+  float bmax[3];
+  uint32_t leftFirst;
+  uint32_t span;
+};
+
+struct LeafTri {           // 48 bytes, leaf order
+  float p0[3]; uint32_t triIdx;
+  float e1[3]; uint32_t matFlags;   // MAT_HAS_ALPHA | MAT_TRANSPARENT of the triangle's material
+  float e2[3]; uint32_t material;
+};
+
+struct MeshDev {
+  uint32_t nodeOffset;     // into bvhNodes
+  uint32_t leafOffset;     // into leafTris
+  uint32_t triOffset;      // into triVerts / triLight
+  uint32_t vertOffset;     // into vertex arrays
+  uint32_t nTris, nVerts, nNodes, pad;
+};
+
+struct NodeDev {           // core/scene.hpp:11-64
+  Xform xf;                // transform (fwd, inv)
+  float bmin[3]; int32_t mesh;
+  float bmax[3]; uint32_t skip;    // next node index when this subtree is culled
+  int32_t parent; uint32_t depth; uint32_t pad[2];
+};
+
+struct LightDev {          // core/light.hpp
+  uint32_t type; int32_t mesh; uint32_t tri; uint32_t twoSided;
+  f3 emission; float area;         // AreaLight::m_area (of the transformed triangle)
+  float power; float radius; int32_t texture; uint32_t envOffset;   // env table index
+  Xform xf;
+};
+
+struct EnvDev {            // ImageInfiniteLight + PiecewiseConstant2D (light.cpp:137-197, sampling.hpp:118-196)
+  uint32_t w, h;           // distribution resolution (= texture resolution for full bounds)
+  uint32_t funcOffset;     // w*h floats   (|f|)
+  uint32_t cdfOffset;      // (w+1)*h floats (conditional CDFs)
+  uint32_t rowIntOffset;   // h floats (conditional integrals = marginal function)
+  uint32_t margCdfOffset;  // h+1 floats
+  float margIntegral;
+  float surfaceArea;       // light.cpp:192-196
+};
+
+struct CameraDev {         // core/camera.hpp:13-59
+  f3 position; float apertureRadius;
+  f3 topLeftPixel; uint32_t apertureSides;
+  f3 pixelDeltaU; float exposureScale;   // exp2(exposure), integrator.cpp:23
+  f3 pixelDeltaV; float pad0;
+  f3 frameX; float pad1;
+  f3 frameY; float pad2;
+  f3 frameZ; float pad3;
+};
+
+struct LutDev {            // bsdf/luts.hpp:14-24 — float offsets into lutData
+  // E[32][32], Eavg[32], baseE[16][16][16], baseEavg[16][16], glassE[16^3], glassEavg[16^2],
+  // glassInvE[16^3], glassInvEavg[16^2], then 52 uint32 of the Sobol dim-1 matrix
+  static constexpr uint32_t E = 0, Eavg = 1024, baseE = 1056, baseEavg = 5152, glassE = 5408,
+                            glassEavg = 9504, glassInvE = 9760, glassInvEavg = 13856,
+                            sobol = 14112, total = 14164;
+};
+
+// Everything a kernel needs, passed by value as a kernel argument (pointers into HBM).
+struct SceneDev {
+  const BvhNode* bvhNodes;
+  const LeafTri* leafTris;
+  const u4* triVerts;          // i0, i1, i2 (mesh-local vertex ids), material
+  const int32_t* triLight;
+  const f4* vPos;              // xyz, pad
+  const f4* vNormal;           // xyz, pad
+  const f4* vTangent;
+  const f2* vUV;
+  const MeshDev* meshes;
+  const NodeDev* nodes;
+  const MaterialDev* materials;
+  const TexDev* textures;
+  const uint8_t* texU8;
+  const float* texF32;
+  const LightDev* lights;
+  const EnvDev* envs;
+  const float* envData;
+  const uint32_t* infiniteLights;   // indices into lights
+  const uint32_t* areaLights;       // indices into lights
+  const float* areaPowerCdf;        // m_lightPowers, light-sampler.cpp:43-47
+  const float* lut;                 // LutDev layout
+  uint32_t nNodes, nLights, nInfinite, nArea;
+  float totalPower;
+  uint32_t pad[3];
+};
+
+struct Hit {                   // cpu/hit.hpp:8-17 after testNode returned
+  float t;
+  f2 uv;
+  f3 p, n, tg;
+  uint32_t material;
+  int32_t lightIdx;
+  bool backSide;
+};
+
+}  // namespace yart_hip

@@ -1,0 +1,273 @@
+// traverse.hpp — scene-graph walk, ordered BVH traversal, ray/triangle and ray/box tests.
+//
+// Restates reference cpu/ray-integrator.cpp:20-261 (testNode, testMesh, testBVH,
+// testTriangle, testBoundingBox) and core/ray.hpp:15-25. The traversal order is
+// the reference's exactly (near child first, far child pushed with its entry
+// distance, pop-cull on d < hit.t, leaf triangles in index order, NEE rays stop a
+// leaf at the first hit but keep walking) because two things depend on it:
+// which of several equal-t triangles wins, and the sampler dimension consumed by
+// stochastic alpha tests inside the traversal (ray-integrator.cpp:207-211).
+//
+// GPU layout decisions (vs the reference's pointer chasing):
+//  * the recursive testNode becomes a linear pre-order walk with skip links;
+//  * an inner visit reads both children with one 64-byte access (nodes are 32 B
+//    and siblings adjacent), a leaf visit streams 48-byte LeafTri records;
+//  * the 64-entry traversal stack lives in LDS, lane-interleaved (8-byte
+//    entries: node index + entry distance), with a global-memory spill area for
+//    the entries beyond LDS_STACK — no overflow is possible up to the
+//    reference's own fixed depth of 64;
+//  * only (t, u, v, slot, node) is tracked during the walk; normals, uvs,
+//    tangents and the object->world chain are evaluated once for the final hit.
+#pragma once
+#include "bsdf.hpp"
+#include "sampler.hpp"
+
+namespace yart_hip {
+
+constexpr uint32_t kRefStackDepth = 64;     // ray-integrator.cpp:92-93
+
+struct RayO {                // core/ray.hpp:9-30 (object-space ray with slab precomputations)
+  f3 o, d, idir, odir;
+  uint32_t sx, sy, sz;
+};
+YART_HD RayO makeRay(f3 o, f3 d) {
+  RayO r; r.o = o; r.d = d;
+  r.idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // "1.0 / dir": double divide narrowed == float divide
+  r.odir = (-o) / d;
+  r.sx = d.x < 0.0f ? 1u : 0u; r.sy = d.y < 0.0f ? 1u : 0u; r.sz = d.z < 0.0f ? 1u : 0u;
+  return r;
+}
+
+// ray-integrator.cpp:231-261
+YART_HD bool testBox(const RayO& r, float tIntMin, float tIntMax, const float* bmin, const float* bmax,
+                     float& d) {
+  float lo_x = r.sx ? bmax[0] : bmin[0], hi_x = r.sx ? bmin[0] : bmax[0];
+  float lo_y = r.sy ? bmax[1] : bmin[1], hi_y = r.sy ? bmin[1] : bmax[1];
+  float lo_z = r.sz ? bmax[2] : bmin[2], hi_z = r.sz ? bmin[2] : bmax[2];
+  float tmin0 = lo_x * r.idir.x + r.odir.x, tmin1 = lo_y * r.idir.y + r.odir.y, tmin2 = lo_z * r.idir.z + r.odir.z;
+  float tmax0 = hi_x * r.idir.x + r.odir.x, tmax1 = hi_y * r.idir.y + r.odir.y, tmax2 = hi_z * r.idir.z + r.odir.z;
+  float t0 = tIntMin, t1 = tIntMax;
+  t0 = ymax(tmin0, t0); t0 = ymax(tmin1, t0); t0 = ymax(tmin2, t0);
+  t1 = ymin(tmax0, t1); t1 = ymin(tmax1, t1); t1 = ymin(tmax2, t1);
+  d = t0;
+  return t1 >= t0;
+}
+
+// Lane-private traversal stack: entry k of this lane is lds[k * ldsStride] for
+// k < ldsDepth, spill[(k - ldsDepth) * spillStride] beyond.
+struct TravStack {
+  uint64_t* lds; uint32_t ldsStride; uint32_t ldsDepth;
+  uint64_t* spill; uint32_t spillStride;
+};
+YART_HD void stackPush(const TravStack& s, uint32_t k, uint32_t node, float d) {
+  uint32_t db; std::memcpy(&db, &d, 4);
+  uint64_t e = uint64_t(node) | (uint64_t(db) << 32);
+  if (k < s.ldsDepth) s.lds[k * s.ldsStride] = e;
+  else s.spill[(k - s.ldsDepth) * s.spillStride] = e;
+}
+YART_HD void stackPop(const TravStack& s, uint32_t k, uint32_t& node, float& d) {
+  uint64_t e = (k < s.ldsDepth) ? s.lds[k * s.ldsStride] : s.spill[(k - s.ldsDepth) * s.spillStride];
+  node = uint32_t(e);
+  uint32_t db = uint32_t(e >> 32);
+  std::memcpy(&d, &db, 4);
+}
+
+struct HitRec {              // what the walk tracks of cpu/hit.hpp
+  float t;                   // in: tMax, out: closest t
+  float u, v;                // barycentrics of p1, p2
+  uint32_t tri;              // mesh-local triangle index (hit.idx)
+  uint32_t node;             // scene node owning the hit
+  uint32_t backSide;
+};
+
+struct AlphaCtx {            // state the stochastic alpha test draws from
+  Sampler* sampler;
+  SamplerConfig cfg;
+};
+
+// uv / normal interpolation of ray-integrator.cpp:198-213
+YART_HD void interpUVN(const SceneDev& sc, const MeshDev& mesh, uint32_t tri, float u, float v, f2& uv,
+                       f3& n) {
+  const u4 tv = sc.triVerts[mesh.triOffset + tri];
+  const float w = 1.0f - u - v;
+  const f2 t0 = sc.vUV[mesh.vertOffset + tv.x], t1 = sc.vUV[mesh.vertOffset + tv.y],
+           t2 = sc.vUV[mesh.vertOffset + tv.z];
+  uv = (w * t0 + u * t1) + v * t2;
+  const f4 a = sc.vNormal[mesh.vertOffset + tv.x], b = sc.vNormal[mesh.vertOffset + tv.y],
+           c = sc.vNormal[mesh.vertOffset + tv.z];
+  n = (w * mk3(a.x, a.y, a.z) + u * mk3(b.x, b.y, b.z)) + v * mk3(c.x, c.y, c.z);
+}
+
+// testBVH (ray-integrator.cpp:84-160) + testTriangle (:163-229) for one mesh.
+template <bool NEE>
+YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t nodeIdx, const RayO& ray,
+                          float tMin, HitRec& hit, f3& attenuation, const TravStack& stk,
+                          AlphaCtx& actx) {
+  const BvhNode* nodes = sc.bvhNodes + mesh.nodeOffset;
+  const LeafTri* leaves = sc.leafTris + mesh.leafOffset;
+  uint32_t node = 0;
+  uint32_t stackIdx = 0;
+  bool didHit = false;
+  float d;
+  {
+    const BvhNode root = nodes[0];
+    if (!testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) return false;
+  }
+  uint32_t leftFirst = nodes[0].leftFirst, span = nodes[0].span;
+  while (true) {
+    if (d < hit.t) {
+      if (span > 0) {
+        for (uint32_t i = 0; i < span; i++) {
+          const LeafTri tr = leaves[leftFirst + i];
+          const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
+          const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
+          const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
+          bool accepted = false;
+          do {
+            const f3 rayEdge2 = cross(ray.d, edge2);
+            const float det = dot(edge1, rayEdge2);
+            if (double(fabsf(det)) < 1e-12) break;          // math_base.hpp:11 epsilon is a double
+            const float invDet = 1.0f / det;
+            const f3 b = ray.o - p0;
+            const float u = dot(b, rayEdge2) * invDet;
+            if (u < 0.0f || u > 1.0f) break;
+            const f3 bEdge1 = cross(b, edge1);
+            const float v = dot(ray.d, bEdge1) * invDet;
+            if (v < 0.0f || u + v > 1.0f) break;
+            const float t = dot(edge2, bEdge1) * invDet;
+            if (t <= tMin || hit.t <= t) break;
+            if (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) {
+              // slow path: alpha cut-outs and NEE-transparent surfaces
+              f2 uv; f3 n;
+              interpUVN(sc, mesh, tr.triIdx, u, v, uv, n);
+              const MaterialDev& mt = sc.materials[tr.material];
+              if (tr.matFlags & MAT_HAS_ALPHA) {
+                float alpha = matAlpha(sc, mt, uv);
+                if (alpha < 1.0f && get1D(*actx.sampler, actx.cfg) > alpha) break;
+              }
+              if (NEE && (tr.matFlags & MAT_TRANSPARENT)) {
+                attenuation *= absDot(n, ray.d) * matBase(sc, mt, uv);
+                break;
+              }
+            }
+            hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeIdx;
+            hit.backSide = det < 0 ? 1u : 0u;
+            accepted = true;
+          } while (false);
+          didHit |= accepted;
+          if (NEE && didHit) break;
+        }
+        if (stackIdx == 0) break;
+        stackPop(stk, --stackIdx, node, d);
+      } else {
+        const BvhNode c1 = nodes[leftFirst], c2 = nodes[leftFirst + 1];
+        float d1, d2;
+        bool hit1 = testBox(ray, tMin, hit.t, c1.bmin, c1.bmax, d1);
+        bool hit2 = testBox(ray, tMin, hit.t, c2.bmin, c2.bmax, d2);
+        uint32_t n1 = leftFirst, n2 = leftFirst + 1;
+        if (hit1) {
+          if (hit2) {
+            if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tn = n1; n1 = n2; n2 = tn; }
+            stackPush(stk, stackIdx++, n2, d2);
+          }
+          node = n1; d = d1;
+          // children are already in registers: take their link fields directly
+          const bool first = (n1 == leftFirst);
+          leftFirst = first ? c1.leftFirst : c2.leftFirst;
+          span = first ? c1.span : c2.span;
+          continue;
+        } else if (hit2) {
+          node = n2; d = d2;
+          leftFirst = c2.leftFirst; span = c2.span;
+          continue;
+        } else {
+          if (stackIdx == 0) break;
+          stackPop(stk, --stackIdx, node, d);
+        }
+      }
+    } else {
+      if (stackIdx == 0) break;
+      stackPop(stk, --stackIdx, node, d);
+    }
+    leftFirst = nodes[node].leftFirst; span = nodes[node].span;
+  }
+  return didHit;
+}
+
+// World ray -> object space of scene node `idx`: the reference re-derives the ray at
+// every level from its parent's object-space ray (ray-integrator.cpp:26-29).
+YART_HD void objectRay(const SceneDev& sc, uint32_t idx, f3 o, f3 d, f3& oo, f3& od) {
+  uint32_t chain[kMaxNodeDepth];
+  uint32_t n = 0;
+  for (int32_t i = int32_t(idx); i >= 0 && n < kMaxNodeDepth; i = sc.nodes[i].parent) chain[n++] = uint32_t(i);
+  for (uint32_t k = n; k-- > 0;) {
+    const NodeDev& nd = sc.nodes[chain[k]];
+    o = mulPoint(nd.xf.inv, o);
+    d = mulVector(nd.xf.inv, d);
+  }
+  oo = o; od = d;
+}
+
+// testNode (ray-integrator.cpp:20-54) as a pre-order walk. hit.t carries tMax in.
+template <bool NEE>
+YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& hit, f3& attenuation,
+                           const TravStack& stk, AlphaCtx& actx) {
+  bool didHit = false;
+  uint32_t i = 0;
+  while (i < sc.nNodes) {
+    const NodeDev& nd = sc.nodes[i];
+    f3 oo, od;
+    objectRay(sc, i, o, d, oo, od);
+    RayO ray = makeRay(oo, od);
+    float dd;
+    if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) { i = nd.skip; continue; }
+    if (nd.mesh >= 0)
+      didHit |= traverseMesh<NEE>(sc, sc.meshes[nd.mesh], i, ray, tMin, hit, attenuation, stk, actx);
+    i++;
+  }
+  return didHit;
+}
+
+// testTriangle's hit fields + testMesh (ray-integrator.cpp:56-82) + the object->world
+// chain of testNode (:50-52) for the final hit.
+YART_HD Hit finalizeHit(const SceneDev& sc, const HitRec& r, f3 o, f3 d) {
+  const NodeDev& nd = sc.nodes[r.node];
+  const MeshDev& mesh = sc.meshes[nd.mesh];
+  f3 oo, od;
+  objectRay(sc, r.node, o, d, oo, od);
+  Hit h;
+  h.t = r.t;
+  f3 n;
+  interpUVN(sc, mesh, r.tri, r.u, r.v, h.uv, n);
+  h.p = oo + (r.t * od);                                   // ray(t), ray.hpp:27-29
+  h.backSide = r.backSide != 0;
+  const u4 tv = sc.triVerts[mesh.triOffset + r.tri];
+  h.material = tv.w;
+  const MaterialDev& mt = sc.materials[h.material];
+  // testMesh: tangents with barycentrics (w,u,v), normal map, tangent rebuilt from n x Y
+  const float w = 1.0f - r.u - r.v;
+  const f4 t0 = sc.vTangent[mesh.vertOffset + tv.x], t1 = sc.vTangent[mesh.vertOffset + tv.y],
+           t2 = sc.vTangent[mesh.vertOffset + tv.z];
+  f4 tg;
+  tg.x = (w * t0.x + r.u * t1.x) + r.v * t2.x;
+  tg.y = (w * t0.y + r.u * t1.y) + r.v * t2.y;
+  tg.z = (w * t0.z + r.u * t1.z) + r.v * t2.z;
+  tg.w = (w * t0.w + r.u * t1.w) + r.v * t2.w;
+  n = bsdfNormal(sc, mt, n, tg, h.uv);
+  f3 tang;
+  if (absDot(n, mk3(0, 1, 0)) > 0.999f) tang = mk3(1, 0, 0);
+  else tang = normalized(cross(n, mk3(0, 1, 0)));
+  h.lightIdx = sc.triLight[mesh.triOffset + r.tri];
+  // up the node chain: p as Point, n as Normal (renormalised per level), tg as Vector
+  f3 p = h.p;
+  for (int32_t i = int32_t(r.node); i >= 0; i = sc.nodes[i].parent) {
+    const NodeDev& a = sc.nodes[i];
+    p = mulPoint(a.xf.fwd, p);
+    n = mulNormalT(a.xf.inv, n);       // m_normalTransform = transpose(float3x3(inverse))
+    tang = mulVector(a.xf.fwd, tang);
+  }
+  h.p = p; h.n = n; h.tg = tang;
+  return h;
+}
+
+}  // namespace yart_hip

@@ -1,0 +1,341 @@
+"""ctypes binding of ``libyart_hip.so`` and a host-side mirror of the reference's
+renderer interface.
+
+The reference's seam is the abstract class ``yart::Renderer`` (reference
+``src/core/renderer.hpp:17-104``) implemented by ``yart::cpu::TileRenderer``
+(``src/cpu/tile-renderer.hpp:22-310``).  :class:`HipTileRenderer` keeps that
+surface — public knobs ``samples / first_wave_samples / max_wave_samples /
+tile_size / background_color / scene``, methods ``render() / abort() / wait() /
+render_sync()`` returning a ``RenderData`` — on top of the C ABI declared in
+``include/yart_hip.h``.
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+visible, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+import time
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import yscn
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyart_hip.so")
+
+YART_OK, YART_E_INVALID, YART_E_NO_DEVICE, YART_E_HIP, YART_E_IO = 0, -1, -2, -3, -4
+FLAG_MEGAKERNEL = 1
+
+
+class YartError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"yart_hip error {code}: {message}")
+        self.code = code
+
+
+# ---------------------------------------------------------------------------
+# POD mirrors of include/yart_hip.h
+# ---------------------------------------------------------------------------
+class TextureDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32),
+                ("is_float", C.c_uint32), ("type", C.c_uint32), ("data", C.c_void_p)]
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [("base", C.c_float * 3), ("emission", C.c_float * 3),
+                ("metallic", C.c_float), ("roughness", C.c_float), ("transmission", C.c_float),
+                ("ior", C.c_float), ("anisotropic", C.c_float), ("aniso_rotation", C.c_float),
+                ("clearcoat", C.c_float), ("clearcoat_roughness", C.c_float),
+                ("normal_scale", C.c_float), ("thin_transmission", C.c_uint32),
+                ("volume_color", C.c_float * 3), ("volume_density", C.c_float),
+                ("tex_base", C.c_int32), ("tex_mr", C.c_int32), ("tex_transmission", C.c_int32),
+                ("tex_normal", C.c_int32), ("tex_clearcoat", C.c_int32), ("tex_emission", C.c_int32)]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_faces", C.c_uint32),
+                ("positions", C.c_void_p), ("normals", C.c_void_p), ("tangents", C.c_void_p),
+                ("uvs", C.c_void_p), ("faces", C.c_void_p), ("face_light", C.c_void_p)]
+
+
+class NodeDesc(C.Structure):
+    _fields_ = [("parent", C.c_int32), ("mesh", C.c_int32), ("fwd", C.c_float * 16), ("inv", C.c_float * 16)]
+
+
+class LightDesc(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("mesh", C.c_int32), ("tri", C.c_uint32), ("two_sided", C.c_uint32),
+                ("texture", C.c_int32), ("radius", C.c_float), ("emission", C.c_float * 3),
+                ("fwd", C.c_float * 16), ("inv", C.c_float * 16)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_textures", C.c_uint32), ("n_materials", C.c_uint32), ("n_meshes", C.c_uint32),
+                ("n_nodes", C.c_uint32), ("n_lights", C.c_uint32),
+                ("textures", C.POINTER(TextureDesc)), ("materials", C.POINTER(MaterialDesc)),
+                ("meshes", C.POINTER(MeshDesc)), ("nodes", C.POINTER(NodeDesc)),
+                ("lights", C.POINTER(LightDesc))]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("focal_length", C.c_float),
+                ("f_number", C.c_float), ("sensor", C.c_float * 2), ("position", C.c_float * 3),
+                ("target", C.c_float * 3), ("up", C.c_float * 3), ("exposure", C.c_float),
+                ("aperture_sides", C.c_uint32)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("samples", C.c_uint32), ("first_wave_samples", C.c_uint32),
+                ("max_wave_samples", C.c_uint32), ("tile_size", C.c_uint32), ("max_depth", C.c_uint32),
+                ("background", C.c_float * 3), ("rank", C.c_uint32), ("world_size", C.c_uint32),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("ms_total", C.c_double),
+                ("ms_device", C.c_double), ("ms_traverse", C.c_double), ("traversals", C.c_uint64),
+                ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("waves", C.c_uint32),
+                ("launches_traverse", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error",
+           "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
+           "yart_hip_render", "yart_hip_render_device", "yart_hip_probe_samples",
+           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy"]
+
+_lib = None
+
+
+def lib():
+    """Load libyart_hip.so (built by ``__graft_entry__.build()``); raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YartError(YART_E_NO_DEVICE, f"{LIB_PATH} not built (run __graft_entry__.build()); "
+                                              "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.yart_hip_last_error.restype = C.c_char_p
+        L.yart_hip_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.yart_hip_scene_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.yart_hip_scene_destroy.argtypes = [C.c_void_p]
+        L.yart_hip_scene_destroy.restype = None
+        L.yart_hip_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
+                                      C.c_void_p, C.POINTER(Stats)]
+        L.yart_hip_render_device.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
+                                             C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.yart_hip_probe_samples.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
+                                             C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.yart_hip_probe_hits.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.yart_hip_bvh_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.yart_hip_bvh_copy.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(code):
+    if code != YART_OK:
+        raise YartError(code, lib().yart_hip_last_error().decode())
+
+
+def _f(arr, n):
+    return (C.c_float * n)(*[float(v) for v in np.asarray(arr, np.float32).reshape(-1)[:n]])
+
+
+def make_camera(p: dict) -> CameraDesc:
+    """``p`` uses the vocabulary of oracle/params.hpp / yart_amd.scenes."""
+    c = CameraDesc()
+    c.width, c.height = int(p["size"][0]), int(p["size"][1])
+    c.focal_length = float(p.get("focal", 35.0)); c.f_number = float(p.get("fnumber", 0.0))
+    c.sensor = _f(p.get("sensor", (36.0, 24.0)), 2)
+    c.position = _f(p["eye"], 3); c.target = _f(p["target"], 3); c.up = _f(p.get("up", (0, 1, 0)), 3)
+    c.exposure = float(p.get("exposure", 0.0)); c.aperture_sides = int(p.get("aperture_sides", 0))
+    return c
+
+
+def make_params(p: dict, rank=0, world_size=1, flags=0) -> RenderParams:
+    r = RenderParams()
+    r.samples = int(p["spp"])
+    r.first_wave_samples = int(p.get("first_wave", p["spp"]))     # single wave, as main.cpp:97-99
+    r.max_wave_samples = int(p.get("max_wave", p["spp"]))
+    r.tile_size = int(p.get("tile", 64)); r.max_depth = int(p.get("depth", 30))
+    r.background = _f(p.get("background", (0, 0, 0)), 3)
+    r.rank, r.world_size, r.flags = int(rank), int(world_size), int(flags)
+    return r
+
+
+class DeviceScene:
+    """Owns a ``YartScene*`` (device-resident flattened scene + BVHs)."""
+
+    def __init__(self, scene, device: int = -1):
+        self._h = C.c_void_p()
+        self._keep = []
+        if isinstance(scene, (str, os.PathLike)):
+            _check(lib().yart_hip_scene_load(os.fspath(scene).encode(), device, C.byref(self._h)))
+        else:
+            desc = self._describe(scene)
+            _check(lib().yart_hip_scene_create(C.byref(desc), device, C.byref(self._h)))
+        self._keep = []     # the library copies everything it needs
+
+    def _describe(self, s: yscn.Scene) -> SceneDesc:
+        keep = self._keep
+
+        def ptr(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype); keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+        tex = (TextureDesc * max(len(s.textures), 1))()
+        for i, t in enumerate(s.textures):
+            tex[i] = TextureDesc(t.width, t.height, t.channels, int(t.is_float), t.type,
+                                 ptr(t.data, np.float32 if t.is_float else np.uint8))
+        mats = (MaterialDesc * max(len(s.materials), 1))()
+        for i, m in enumerate(s.materials):
+            C.memmove(C.byref(mats[i]), m.pack(), C.sizeof(MaterialDesc))
+        meshes = (MeshDesc * max(len(s.meshes), 1))()
+        for i, m in enumerate(s.meshes):
+            meshes[i] = MeshDesc(len(m.positions), len(m.faces), ptr(m.positions, np.float32),
+                                 ptr(m.normals, np.float32), ptr(m.tangents, np.float32),
+                                 ptr(m.uvs, np.float32), ptr(m.faces, np.uint32), ptr(m.face_light, np.int32))
+        nodes = (NodeDesc * len(s.nodes))()
+        for i, n in enumerate(s.nodes):
+            nodes[i] = NodeDesc(n.parent, n.mesh, _f(n.fwd, 16), _f(n.inv, 16))
+        lights = (LightDesc * max(len(s.lights), 1))()
+        for i, l in enumerate(s.lights):
+            lights[i] = LightDesc(l.type, l.mesh, l.tri, int(l.two_sided), l.texture, l.radius,
+                                  _f(l.emission, 3), _f(l.fwd, 16), _f(l.inv, 16))
+        keep += [tex, mats, meshes, nodes, lights]
+        return SceneDesc(len(s.textures), len(s.materials), len(s.meshes), len(s.nodes), len(s.lights),
+                         tex, mats, meshes, nodes, lights)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            lib().yart_hip_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- rendering ----------------------------------------------------------------
+    def render(self, p: dict, rank=0, world_size=1, flags=0):
+        """Blocking render to a host array (H, W, 4) float32 + stats dict."""
+        cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
+        out = np.empty((cam.height, cam.width, 4), np.float32)
+        _check(lib().yart_hip_render(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p),
+                                     C.byref(st)))
+        return out, st.asdict()
+
+    def render_into(self, tensor, p: dict, rank=0, world_size=1, flags=0, stream=None):
+        """Render into a CUDA/HIP torch tensor of shape (H, W, 4) float32 (device memory)."""
+        cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == cam.width * cam.height * 4
+        sp = C.c_void_p(stream) if stream else None
+        _check(lib().yart_hip_render_device(self._h, C.byref(cam), C.byref(rp),
+                                            C.c_void_p(tensor.data_ptr()), sp, C.byref(st)))
+        return st.asdict()
+
+    # -- diagnostics ----------------------------------------------------------------
+    def probe_samples(self, p: dict, xys: Sequence[Sequence[int]]):
+        cam, rp = make_camera(p), make_params(p)
+        a = np.ascontiguousarray(xys, np.uint32).reshape(-1, 3)
+        out = np.empty((len(a), 3), np.float32)
+        rays = C.c_uint64()
+        _check(lib().yart_hip_probe_samples(self._h, C.byref(cam), C.byref(rp), len(a),
+                                            a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                            C.byref(rays)))
+        return out, rays.value
+
+    def probe_hits(self, rays):
+        a = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.empty((len(a), 16), np.float32)
+        _check(lib().yart_hip_probe_hits(self._h, len(a), a.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def bvh(self, mesh: int):
+        nn, nt = C.c_uint32(), C.c_uint32()
+        _check(lib().yart_hip_bvh_info(self._h, mesh, C.byref(nn), C.byref(nt)))
+        nodes = np.empty((nn.value, 8), np.uint32); idx = np.empty(nt.value, np.uint32)
+        _check(lib().yart_hip_bvh_copy(self._h, mesh, nodes.ctypes.data_as(C.c_void_p),
+                                       idx.ctypes.data_as(C.c_void_p)))
+        return nodes, idx
+
+
+@dataclass
+class RenderData:
+    """Mirror of ``yart::Renderer::RenderData`` (reference src/core/renderer.hpp:22-28)."""
+    buffer: np.ndarray
+    samples_taken: int
+    total_samples: int
+    total_rays: int
+    total_time_ms: float
+    stats: dict
+
+
+class HipTileRenderer:
+    """Drop-in for ``yart::cpu::TileRenderer<SobolSampler<FastOwenScrambler>, MISIntegrator>``
+    (reference src/cpu/tile-renderer.hpp:25-115): same knobs, same blocking / async calls.
+
+    ``camera`` is a dict in the vocabulary of ``oracle/params.hpp`` (size, focal, fnumber,
+    sensor, eye, target, up, exposure, aperture_sides)."""
+
+    def __init__(self, width: int, height: int, camera: dict, device: int = -1):
+        self.samples = 64                 # DEFAULT_SAMPLE_COUNT, tile-renderer.hpp:10-13
+        self.first_wave_samples = 64
+        self.max_wave_samples = 128
+        self.tile_size = 64
+        self.max_depth = 30               # RayIntegrator::m_maxDepth, ray-integrator.hpp:14
+        self.background_color = (0.0, 0.0, 0.0)
+        self.scene: Optional[DeviceScene] = None
+        self.tonemapper = None            # stays on the host (reference core/tonemapping.hpp); unused here
+        self.on_render_complete = None    # callbacks of renderer.hpp:55-58 (wave/tile granularity
+        self.on_render_aborted = None     # collapses to one call: the GPU renders a wave per launch)
+        self._camera = dict(camera, size=(width, height))
+        self._device = device
+        self._thread: Optional[threading.Thread] = None
+        self._abort = False
+        self._result: Optional[RenderData] = None
+
+    def _params(self):
+        return dict(self._camera, spp=self.samples, first_wave=min(self.first_wave_samples, self.samples),
+                    max_wave=self.max_wave_samples, tile=self.tile_size, depth=self.max_depth,
+                    background=self.background_color)
+
+    def render_sync(self) -> RenderData:
+        if self.scene is None:           # Integrator::render: "if (!scene) return" (integrator.cpp:6)
+            w, h = self._camera["size"]
+            return RenderData(np.zeros((h, w, 4), np.float32), 0, self.samples, 0, 0.0, {})
+        t0 = time.perf_counter()
+        buf, st = self.scene.render(self._params())
+        ms = (time.perf_counter() - t0) * 1e3
+        self._result = RenderData(buf, self.samples, self.samples, st["rays"], ms, st)
+        return self._result
+
+    def render(self):
+        self._abort = False
+
+        def run():
+            r = self.render_sync()
+            cb = self.on_render_aborted if self._abort else self.on_render_complete
+            if cb:
+                cb(r)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def abort(self):
+        self._abort = True               # checked between waves in the reference; a GPU wave is one launch
+
+    def wait(self):
+        if self._thread:
+            self._thread.join()

@@ -85,13 +85,14 @@ struct Sampler {
   uint32_t dim;
 };
 
-// permutations[24][4] of sampler.hpp:115-140, 2 bits per entry, 8 bits per row
+// permutations[24][4] of sampler.hpp:115-140, 2 bits per entry, one byte per row,
+// eight rows per 64-bit word (register-resident: no table memory on the GPU)
 YART_HD uint32_t permutationRow(uint32_t p) {
-  // rows packed little-endian: digit d -> (row >> (2*d)) & 3
-  const uint8_t rows[24] = {
-    0xE4, 0xB4, 0xD8, 0x78, 0x6C, 0x9C, 0xE1, 0xB1, 0xC9, 0x39, 0x2D, 0x8D,
-    0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93};
-  return rows[p];
+  // row bytes: E4 B4 D8 78 6C 9C E1 B1 | C9 39 2D 8D C6 36 D2 72 | 4E 1E 27 87 1B 4B 63 93
+  const uint64_t t0 = 0xB1E19C6C78D8B4E4ull, t1 = 0x72D236C68D2D39C9ull, t2 = 0x93634B1B87271E4Eull;
+  const uint32_t sel = p >> 3;
+  const uint64_t t = sel == 0 ? t0 : (sel == 1 ? t1 : t2);
+  return uint32_t(t >> ((p & 7u) * 8u)) & 0xffu;   // digit d -> (row >> (2*d)) & 3
 }
 
 YART_HD void startPixelSample(Sampler& s, const SamplerConfig& c, uint32_t px, uint32_t py,

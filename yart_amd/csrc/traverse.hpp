@@ -60,7 +60,7 @@ struct TravStack {
   uint64_t* spill; uint32_t spillStride;
 };
 YART_HD void stackPush(const TravStack& s, uint32_t k, uint32_t node, float d) {
-  uint32_t db; std::memcpy(&db, &d, 4);
+  uint32_t db = __builtin_bit_cast(uint32_t, d);
   uint64_t e = uint64_t(node) | (uint64_t(db) << 32);
   if (k < s.ldsDepth) s.lds[k * s.ldsStride] = e;
   else s.spill[(k - s.ldsDepth) * s.spillStride] = e;
@@ -68,8 +68,7 @@ YART_HD void stackPush(const TravStack& s, uint32_t k, uint32_t node, float d) {
 YART_HD void stackPop(const TravStack& s, uint32_t k, uint32_t& node, float& d) {
   uint64_t e = (k < s.ldsDepth) ? s.lds[k * s.ldsStride] : s.spill[(k - s.ldsDepth) * s.spillStride];
   node = uint32_t(e);
-  uint32_t db = uint32_t(e >> 32);
-  std::memcpy(&d, &db, 4);
+  d = __builtin_bit_cast(float, uint32_t(e >> 32));
 }
 
 struct HitRec {              // what the walk tracks of cpu/hit.hpp

@@ -1,0 +1,569 @@
+// yart_hip.hip — gfx950 kernels and the C ABI of libyart_hip.so.
+//
+// Stands where reference cpu/tile-renderer.hpp:118-309 (TileRenderer::renderImpl /
+// finishTile) and cpu/integrator.cpp:5-28 (Integrator::render) stand: tiles of the
+// image are rendered for `waveSamples` samples per pixel, each pixel's samples go
+// through GMoN, and waves are blended into the HDR framebuffer. The thread pool of
+// the reference becomes a persistent grid; the per-sample work is in integrator.hpp.
+//
+// Kernels in this file
+//   k_render_mega   one lane = one (pixel, sample) path from camera to termination
+//                   (BASELINE config "megakernel integrator"); persistent waves pull
+//                   64 paths at a time from an atomic cursor; LDS traversal stack.
+//   k_gmon_blend    one wave = one pixel: bucket sums in sample order, GMoN value,
+//                   blend into the HDR buffer (integrator.cpp:17-25, tile-renderer.hpp:220-232).
+//   k_probe_*       diagnostics used by the parity tests.
+// The wavefront (queue-based) pipeline lives in wavefront.hip.inc.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/yart_hip.h"
+#include "estimator.hpp"
+#include "host_scene.hpp"
+#include "integrator.hpp"
+#include "scene_file.hpp"
+
+using namespace yart_hip;
+
+namespace {
+
+constexpr int kBlock = 256;            // 4 waves per workgroup
+constexpr int kLdsStack = 24;          // traversal stack entries kept in LDS per lane (8 B each)
+constexpr int kSpillDepth = int(kRefStackDepth) - kLdsStack;
+
+thread_local std::string g_lastError;
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define HIP_CHECK(expr)                                                                     \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void ensure(size_t count) {
+    if (count <= n) return;
+    release();
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    n = count;
+  }
+  void upload(const std::vector<T>& v) {
+    ensure(std::max<size_t>(v.size(), 1));
+    if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------
+struct MegaArgs {
+  SceneDev sc;
+  CameraDev cam;
+  RenderConst rc;
+  const uint32_t* pixels;      // packed x | y << 16, tile-major order
+  uint32_t nPixels, spp, sampleOffset, pad;
+  float* L;                    // 3 floats per (pixel, sample)
+  uint32_t* cursor;
+  unsigned long long* rays;
+  uint64_t* spill;             // kSpillDepth entries per launched thread, lane-interleaved
+};
+
+__global__ void __launch_bounds__(kBlock) k_render_mega(MegaArgs a) {
+  __shared__ uint64_t ldsStack[kLdsStack * kBlock];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nthreads = gridDim.x * blockDim.x;
+  PathCtx cx;
+  cx.sc = &a.sc;
+  cx.sobol = reinterpret_cast<const uint32_t*>(a.sc.lut + LutDev::sobol);
+  cx.stk.lds = ldsStack + threadIdx.x; cx.stk.ldsStride = kBlock; cx.stk.ldsDepth = kLdsStack;
+  cx.stk.spill = a.spill + gtid; cx.stk.spillStride = nthreads;
+  cx.rc = a.rc;
+  const uint32_t total = a.nPixels * a.spp;
+  uint32_t rays = 0;
+  for (;;) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.cursor, 64u);
+    base = __shfl(base, 0);
+    if (base >= total) break;            // wave-uniform exit: every wave drains the cursor
+    const uint32_t w = base + lane;
+    if (w < total) {
+      const uint32_t pi = w / a.spp, s = w - pi * a.spp;
+      const uint32_t pk = a.pixels[pi];
+      f3 L = samplePixel(cx, a.cam, pk & 0xffffu, pk >> 16, s + a.sampleOffset, rays);
+      a.L[size_t(w) * 3 + 0] = L.x; a.L[size_t(w) * 3 + 1] = L.y; a.L[size_t(w) * 3 + 2] = L.z;
+    }
+  }
+  // one atomic per wave
+  unsigned long long r = rays;
+  for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o);
+  if (lane == 0 && r) atomicAdd(a.rays, r);
+}
+
+struct GmonArgs {
+  const float* L;
+  const uint32_t* pixels;
+  uint32_t nPixels, spp, width, pad;
+  float exposureScale, wCurrent, wWave, pad1;
+  float* hdr;                  // RGBA32F, width * height
+};
+
+__global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
+  __shared__ float sAcc[kBlock / 64][kGmonMax][4];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t pi = blockIdx.x * (kBlock / 64) + wv;
+  if (pi >= a.nPixels) return;           // whole wave exits together
+  const int m = gmonBuckets(int32_t(a.spp));
+  if (int(lane) < m) {
+    f3 acc = mk3(0); uint32_t cnt = 0;
+    const float* p = a.L + size_t(pi) * a.spp * 3;
+    for (uint32_t s = lane; s < a.spp; s += uint32_t(m)) {      // bucket k mod m, increasing k
+      f3 v = mk3(p[s * 3], p[s * 3 + 1], p[s * 3 + 2]) * a.exposureScale;
+      if (gmonAccepts(v)) { acc += v; cnt++; }
+    }
+    sAcc[wv][lane][0] = acc.x; sAcc[wv][lane][1] = acc.y; sAcc[wv][lane][2] = acc.z;
+    sAcc[wv][lane][3] = __uint_as_float(cnt);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  if (lane == 0) {
+    f3 acc[kGmonMax]; uint32_t cnt[kGmonMax];
+    for (int b = 0; b < m; b++) {
+      acc[b] = mk3(sAcc[wv][b][0], sAcc[wv][b][1], sAcc[wv][b][2]);
+      cnt[b] = __float_as_uint(sAcc[wv][b][3]);
+    }
+    f3 v = gmonFinish(acc, cnt, m);
+    const uint32_t pk = a.pixels[pi];
+    float* o = a.hdr + (size_t(pk >> 16) * a.width + (pk & 0xffffu)) * 4;
+    // m_hdrBuffer = current * wCurrent + wave * wWave   (tile-renderer.hpp:230)
+    o[0] = o[0] * a.wCurrent + v.x * a.wWave;
+    o[1] = o[1] * a.wCurrent + v.y * a.wWave;
+    o[2] = o[2] * a.wCurrent + v.z * a.wWave;
+    o[3] = o[3] * a.wCurrent + 1.0f * a.wWave;
+  }
+}
+
+struct ProbeSampleArgs {
+  SceneDev sc; CameraDev cam; RenderConst rc;
+  const uint32_t* xys; uint32_t n; float* out; unsigned long long* rays; uint64_t* spill;
+};
+__global__ void __launch_bounds__(kBlock) k_probe_samples(ProbeSampleArgs a) {
+  __shared__ uint64_t ldsStack[kLdsStack * kBlock];
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  PathCtx cx;
+  cx.sc = &a.sc;
+  cx.sobol = reinterpret_cast<const uint32_t*>(a.sc.lut + LutDev::sobol);
+  cx.stk.lds = ldsStack + threadIdx.x; cx.stk.ldsStride = kBlock; cx.stk.ldsDepth = kLdsStack;
+  cx.stk.spill = a.spill + gtid; cx.stk.spillStride = gridDim.x * blockDim.x;
+  cx.rc = a.rc;
+  if (gtid >= a.n) return;
+  uint32_t rays = 0;
+  f3 L = samplePixel(cx, a.cam, a.xys[gtid * 3], a.xys[gtid * 3 + 1], a.xys[gtid * 3 + 2], rays);
+  a.out[gtid * 3] = L.x; a.out[gtid * 3 + 1] = L.y; a.out[gtid * 3 + 2] = L.z;
+  atomicAdd(a.rays, (unsigned long long) rays);
+}
+
+struct ProbeHitArgs { SceneDev sc; const float* rays; uint32_t n; float* out; uint64_t* spill; };
+__global__ void __launch_bounds__(kBlock) k_probe_hits(ProbeHitArgs a) {
+  __shared__ uint64_t ldsStack[kLdsStack * kBlock];
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  TravStack stk;
+  stk.lds = ldsStack + threadIdx.x; stk.ldsStride = kBlock; stk.ldsDepth = kLdsStack;
+  stk.spill = a.spill + gtid; stk.spillStride = gridDim.x * blockDim.x;
+  if (gtid >= a.n) return;
+  const float* r = a.rays + size_t(gtid) * 6;
+  f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
+  HitRec hr; hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
+  f3 att = mk3(1.0f);
+  Sampler dummy; dummy.dim = 0; dummy.morton = 0;
+  AlphaCtx ac; ac.sampler = &dummy; ac.cfg.log2spp = 0; ac.cfg.nBase4Digits = 6;
+  bool hit = traverseScene<false>(a.sc, o, d, 0.001f, hr, att, stk, ac);
+  float* q = a.out + size_t(gtid) * 16;
+  for (int i = 0; i < 16; i++) q[i] = 0.0f;
+  q[0] = hit ? 1.0f : 0.0f;
+  if (hit) {
+    Hit h = finalizeHit(a.sc, hr, o, d);
+    q[1] = h.t; q[2] = hr.u; q[3] = hr.v;
+    q[4] = h.p.x; q[5] = h.p.y; q[6] = h.p.z; q[7] = h.n.x; q[8] = h.n.y; q[9] = h.n.z;
+    q[10] = h.tg.x; q[11] = h.tg.y; q[12] = h.tg.z;
+    q[13] = float(hr.tri); q[14] = float(h.lightIdx); q[15] = h.backSide ? 1.0f : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct Timer {
+  hipEvent_t a{}, b{};
+  Timer() { HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); }
+  ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+};
+
+}  // namespace
+
+struct YartScene {
+  int device = 0;
+  HostImage host;
+  SceneDev dev{};
+  int numCUs = 256;
+  // device copies of the scene image
+  DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
+  DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
+  DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32;
+  DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData;
+  DevBuf<uint32_t> infiniteLights, areaLights; DevBuf<float> areaPowerCdf; DevBuf<float> lut;
+  // render scratch (grown on demand, reused across calls)
+  DevBuf<uint32_t> pixels; DevBuf<float> L; DevBuf<uint32_t> cursor; DevBuf<unsigned long long> counters;
+  DevBuf<uint64_t> spill; DevBuf<float> hdr; DevBuf<uint32_t> probeIn; DevBuf<float> probeOut;
+  std::vector<uint32_t> pixelsHost;
+  uint32_t pixW = 0, pixH = 0, pixTile = 0, pixRank = 0, pixWorld = 0;
+  std::mutex mu;
+};
+
+namespace {
+
+void uploadScene(YartScene& s) {
+  const HostImage& h = s.host;
+  s.bvhNodes.upload(h.bvhNodes); s.leafTris.upload(h.leafTris); s.triVerts.upload(h.triVerts);
+  s.triLight.upload(h.triLight); s.vPos.upload(h.vPos); s.vNormal.upload(h.vNormal);
+  s.vTangent.upload(h.vTangent); s.vUV.upload(h.vUV); s.meshes.upload(h.meshes); s.nodes.upload(h.nodes);
+  s.materials.upload(h.materials); s.textures.upload(h.textures); s.texU8.upload(h.texU8);
+  s.texF32.upload(h.texF32); s.lights.upload(h.lights); s.envs.upload(h.envs); s.envData.upload(h.envData);
+  s.infiniteLights.upload(h.infiniteLights); s.areaLights.upload(h.areaLights);
+  s.areaPowerCdf.upload(h.areaPowerCdf); s.lut.upload(h.lut);
+  SceneDev d = h.view();       // counts and totals; pointers replaced below
+  d.bvhNodes = s.bvhNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
+  d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
+  d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
+  d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.lights = s.lights.p; d.envs = s.envs.p;
+  d.envData = s.envData.p; d.infiniteLights = s.infiniteLights.p; d.areaLights = s.areaLights.p;
+  d.areaPowerCdf = s.areaPowerCdf.p; d.lut = s.lut.p;
+  s.dev = d;
+}
+
+int resolveDevice(int device) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return -1;
+  if (device < 0) {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return -1;
+    return cur;
+  }
+  return device < count ? device : -1;
+}
+
+YartScene* createScene(const YartSceneDesc& desc, int device) {
+  int dev = resolveDevice(device);
+  if (dev < 0) throw HipError("no usable HIP device (libyart_hip has no CPU fallback)");
+  HIP_CHECK(hipSetDevice(dev));
+  auto s = std::make_unique<YartScene>();
+  s->device = dev;
+  s->host = buildHostImage(desc);
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  s->numCUs = prop.multiProcessorCount;
+  uploadScene(*s);
+  return s.release();
+}
+
+uint32_t morton2(uint32_t x, uint32_t y) { return uint32_t(encodeMorton2(x, y)); }
+
+// Pixels of the tiles this rank owns, tile-major (row-major inside a tile). Tiles are
+// the reference's unit of parallel work (tile-renderer.hpp:126-144); across ranks they
+// are dealt round-robin in Morton order.
+void buildPixelList(YartScene& s, uint32_t W, uint32_t H, uint32_t tile, uint32_t rank, uint32_t world) {
+  if (s.pixW == W && s.pixH == H && s.pixTile == tile && s.pixRank == rank && s.pixWorld == world) return;
+  const uint32_t tx = (W + tile - 1) / tile, ty = (H + tile - 1) / tile;
+  std::vector<std::pair<uint32_t, uint32_t>> order;   // (morton, linear tile)
+  for (uint32_t y = 0; y < ty; y++)
+    for (uint32_t x = 0; x < tx; x++) order.push_back({morton2(x, y), y * tx + x});
+  std::sort(order.begin(), order.end());
+  s.pixelsHost.clear();
+  for (size_t k = 0; k < order.size(); k++) {
+    if (k % world != rank) continue;
+    const uint32_t x0 = (order[k].second % tx) * tile, y0 = (order[k].second / tx) * tile;
+    const uint32_t x1 = std::min(W, x0 + tile), y1 = std::min(H, y0 + tile);
+    for (uint32_t y = y0; y < y1; y++)
+      for (uint32_t x = x0; x < x1; x++) s.pixelsHost.push_back(x | (y << 16));
+  }
+  s.pixels.upload(s.pixelsHost);
+  s.pixW = W; s.pixH = H; s.pixTile = tile; s.pixRank = rank; s.pixWorld = world;
+}
+
+void validate(const YartCameraDesc* cam, const YartRenderParams* p) {
+  require(cam && p, "camera / params pointer is null");
+  require(cam->width > 0 && cam->height > 0 && cam->width < 65536 && cam->height < 65536,
+          "image size must be in [1, 65535]");
+  require(p->samples > 0 && p->first_wave_samples > 0 && p->max_wave_samples > 0, "sample counts must be > 0");
+  require(p->tile_size > 0 && p->tile_size <= 4096, "tile_size out of range");
+  require(p->world_size > 0 && p->rank < p->world_size, "rank / world_size");
+  require(p->max_depth > 0, "max_depth must be > 0");
+}
+
+RenderConst makeRenderConst(const YartRenderParams& p) {
+  RenderConst rc;
+  // the sampler is constructed with the TOTAL sample count and the tile size
+  // (tile-renderer.hpp:153-156)
+  rc.sampler = makeSamplerConfig(p.samples, p.tile_size);
+  rc.maxDepth = p.max_depth;
+  rc.background = mk3(p.background[0], p.background[1], p.background[2]);
+  return rc;
+}
+
+int persistentGrid(const YartScene& s, const void* kernel) {
+  int perCU = 0;
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, 0));
+  if (perCU < 1) perCU = 1;
+  if (perCU > 3) perCU = 3;     // LDS stack: 48 KiB per workgroup -> 3 per CU
+  return s.numCUs * perCU;
+}
+
+void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRenderParams& p, float* dOut,
+                    hipStream_t stream, YartStats* stats) {
+  auto wall0 = std::chrono::high_resolution_clock::now();
+  HIP_CHECK(hipSetDevice(s.device));
+  const uint32_t W = camDesc.width, H = camDesc.height;
+  const CameraDev cam = makeCamera(camDesc);
+  const RenderConst rc = makeRenderConst(p);
+  buildPixelList(s, W, H, p.tile_size, p.rank, p.world_size);
+  const uint32_t nPix = uint32_t(s.pixelsHost.size());
+
+  HIP_CHECK(hipMemsetAsync(dOut, 0, size_t(W) * H * 4 * sizeof(float), stream));
+  s.cursor.ensure(1); s.counters.ensure(8);
+  HIP_CHECK(hipMemsetAsync(s.counters.p, 0, 8 * sizeof(unsigned long long), stream));
+
+  const int grid = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega));
+  s.spill.ensure(size_t(grid) * kBlock * kSpillDepth);
+
+  // chunk the pixel list so that the per-sample radiance buffer stays <= ~1.5 GiB
+  const uint32_t maxWave = std::min(p.max_wave_samples, p.samples);
+  const uint32_t waveCap = std::max(std::min(p.first_wave_samples, p.samples), maxWave);
+  uint64_t budgetFloats = (1536ull << 20) / 4;
+  uint32_t chunk = uint32_t(std::min<uint64_t>(nPix ? nPix : 1, std::max<uint64_t>(budgetFloats / (3ull * waveCap), 64)));
+  while (uint64_t(chunk) * waveCap >= (1ull << 31)) chunk /= 2;
+  s.L.ensure(size_t(chunk) * waveCap * 3);
+
+  Timer tAll, tK;
+  double msTraverse = 0.0;
+  uint32_t launches = 0, waves = 0;
+  HIP_CHECK(hipEventRecord(tAll.a, stream));
+
+  // wave schedule of tile-renderer.hpp:121-124, 284-289
+  uint64_t remaining = p.samples;
+  uint64_t waveSamples = std::min<uint64_t>(p.first_wave_samples, p.samples);
+  uint64_t currentWave = 0;
+  while (waveSamples > 0) {
+    const uint64_t takenBefore = p.samples - remaining, takenAfter = takenBefore + waveSamples;
+    const float wCurrent = float(takenBefore) / float(takenAfter);
+    const float wWave = float(waveSamples) / float(takenAfter);
+    for (uint32_t c0 = 0; c0 < nPix; c0 += chunk) {
+      const uint32_t n = std::min(chunk, nPix - c0);
+      HIP_CHECK(hipMemsetAsync(s.cursor.p, 0, sizeof(uint32_t), stream));
+      MegaArgs a{};
+      a.sc = s.dev; a.cam = cam; a.rc = rc; a.pixels = s.pixels.p + c0; a.nPixels = n;
+      a.spp = uint32_t(waveSamples); a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p;
+      a.cursor = s.cursor.p; a.rays = s.counters.p; a.spill = s.spill.p;
+      HIP_CHECK(hipEventRecord(tK.a, stream));
+      hipLaunchKernelGGL(k_render_mega, dim3(grid), dim3(kBlock), 0, stream, a);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipEventRecord(tK.b, stream));
+      GmonArgs g{};
+      g.L = s.L.p; g.pixels = s.pixels.p + c0; g.nPixels = n; g.spp = uint32_t(waveSamples); g.width = W;
+      g.exposureScale = cam.exposureScale; g.wCurrent = wCurrent; g.wWave = wWave; g.hdr = dOut;
+      hipLaunchKernelGGL(k_gmon_blend, dim3((n + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, stream, g);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipEventSynchronize(tK.b));
+      float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, tK.a, tK.b));
+      msTraverse += ms; launches++;
+    }
+    remaining -= waveSamples;
+    uint64_t next = (currentWave > 0 || waveSamples > 1) ? std::min<uint64_t>(waveSamples * 2, p.max_wave_samples) : 1;
+    waveSamples = std::min(next, remaining);
+    currentWave++; waves++;
+  }
+  HIP_CHECK(hipEventRecord(tAll.b, stream));
+  HIP_CHECK(hipEventSynchronize(tAll.b));
+  float msAll = 0; HIP_CHECK(hipEventElapsedTime(&msAll, tAll.a, tAll.b));
+  unsigned long long rays = 0;
+  HIP_CHECK(hipMemcpy(&rays, s.counters.p, sizeof(rays), hipMemcpyDeviceToHost));
+  if (stats) {
+    *stats = YartStats{};
+    stats->samples = uint64_t(nPix) * p.samples;
+    stats->rays = rays;
+    stats->ms_device = msAll;
+    stats->ms_traverse = msTraverse;
+    stats->waves = waves;
+    stats->launches_traverse = launches;
+    stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
+  }
+}
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return YART_OK;
+  } catch (const std::invalid_argument& e) {
+    g_lastError = e.what(); return YART_E_INVALID;
+  } catch (const HipError& e) {
+    g_lastError = e.what();
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return YART_E_NO_DEVICE;
+    return YART_E_HIP;
+  } catch (const std::exception& e) {
+    g_lastError = e.what(); return YART_E_IO;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int yart_hip_abi_version(void) { return YART_HIP_ABI_VERSION; }
+
+int yart_hip_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+const char* yart_hip_last_error(void) { return g_lastError.c_str(); }
+
+int yart_hip_scene_create(const YartSceneDesc* desc, int device, YartScene** out) {
+  return guarded([&] {
+    require(desc && out, "desc / out pointer is null");
+    *out = createScene(*desc, device);
+  });
+}
+
+int yart_hip_scene_load(const char* path, int device, YartScene** out) {
+  return guarded([&] {
+    require(path && out, "path / out pointer is null");
+    auto loaded = loadSceneFile(path);
+    *out = createScene(loaded->desc, device);
+  });
+}
+
+void yart_hip_scene_destroy(YartScene* scene) {
+  if (!scene) return;
+  (void)hipSetDevice(scene->device);
+  delete scene;
+}
+
+int yart_hip_render_device(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                           float* d_out_rgba, void* stream, YartStats* stats) {
+  return guarded([&] {
+    require(scene && d_out_rgba, "scene / output pointer is null");
+    validate(cam, params);
+    std::lock_guard<std::mutex> lock(scene->mu);
+    renderToDevice(*scene, *cam, *params, d_out_rgba, static_cast<hipStream_t>(stream), stats);
+  });
+}
+
+int yart_hip_render(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                    float* out_rgba, YartStats* stats) {
+  return guarded([&] {
+    require(scene && out_rgba, "scene / output pointer is null");
+    validate(cam, params);
+    std::lock_guard<std::mutex> lock(scene->mu);
+    auto t0 = std::chrono::high_resolution_clock::now();
+    HIP_CHECK(hipSetDevice(scene->device));
+    const size_t n = size_t(cam->width) * cam->height * 4;
+    scene->hdr.ensure(n);
+    renderToDevice(*scene, *cam, *params, scene->hdr.p, nullptr, stats);
+    HIP_CHECK(hipMemcpy(out_rgba, scene->hdr.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (stats)
+      stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+  });
+}
+
+int yart_hip_probe_samples(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                           uint32_t n, const uint32_t* xys, float* out_rgb, uint64_t* out_rays) {
+  return guarded([&] {
+    require(scene && xys && out_rgb, "null pointer");
+    validate(cam, params);
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lock(scene->mu);
+    YartScene& s = *scene;
+    HIP_CHECK(hipSetDevice(s.device));
+    const int grid = int((n + kBlock - 1) / kBlock);
+    s.spill.ensure(size_t(grid) * kBlock * kSpillDepth);
+    s.probeIn.ensure(size_t(n) * 3); s.probeOut.ensure(size_t(n) * 3); s.counters.ensure(8);
+    HIP_CHECK(hipMemcpy(s.probeIn.p, xys, size_t(n) * 3 * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(s.counters.p, 0, 8 * sizeof(unsigned long long)));
+    ProbeSampleArgs a{};
+    a.sc = s.dev; a.cam = makeCamera(*cam); a.rc = makeRenderConst(*params);
+    a.xys = s.probeIn.p; a.n = n; a.out = s.probeOut.p; a.rays = s.counters.p; a.spill = s.spill.p;
+    hipLaunchKernelGGL(k_probe_samples, dim3(grid), dim3(kBlock), 0, nullptr, a);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out_rgb, s.probeOut.p, size_t(n) * 3 * 4, hipMemcpyDeviceToHost));
+    if (out_rays) {
+      unsigned long long r = 0;
+      HIP_CHECK(hipMemcpy(&r, s.counters.p, sizeof(r), hipMemcpyDeviceToHost));
+      *out_rays = r;
+    }
+  });
+}
+
+int yart_hip_probe_hits(YartScene* scene, uint32_t n, const float* rays, float* out) {
+  return guarded([&] {
+    require(scene && rays && out, "null pointer");
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lock(scene->mu);
+    YartScene& s = *scene;
+    HIP_CHECK(hipSetDevice(s.device));
+    const int grid = int((n + kBlock - 1) / kBlock);
+    s.spill.ensure(size_t(grid) * kBlock * kSpillDepth);
+    DevBuf<float> in, res;
+    in.ensure(size_t(n) * 6); res.ensure(size_t(n) * 16);
+    HIP_CHECK(hipMemcpy(in.p, rays, size_t(n) * 6 * 4, hipMemcpyHostToDevice));
+    ProbeHitArgs a{};
+    a.sc = s.dev; a.rays = in.p; a.n = n; a.out = res.p; a.spill = s.spill.p;
+    hipLaunchKernelGGL(k_probe_hits, dim3(grid), dim3(kBlock), 0, nullptr, a);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, res.p, size_t(n) * 16 * 4, hipMemcpyDeviceToHost));
+  });
+}
+
+int yart_hip_bvh_info(YartScene* scene, uint32_t mesh, uint32_t* n_nodes, uint32_t* n_tris) {
+  return guarded([&] {
+    require(scene && n_nodes && n_tris, "null pointer");
+    require(mesh < scene->host.meshes.size(), "mesh index out of range");
+    *n_nodes = scene->host.meshes[mesh].nNodes;
+    *n_tris = scene->host.meshes[mesh].nTris;
+  });
+}
+
+int yart_hip_bvh_copy(YartScene* scene, uint32_t mesh, uint32_t* nodes_out, uint32_t* indices_out) {
+  return guarded([&] {
+    require(scene && nodes_out && indices_out, "null pointer");
+    require(mesh < scene->host.meshes.size(), "mesh index out of range");
+    const MeshDev& m = scene->host.meshes[mesh];
+    // read the node array back from the DEVICE copy: this is what the kernels traverse
+    HIP_CHECK(hipSetDevice(scene->device));
+    HIP_CHECK(hipMemcpy(nodes_out, scene->bvhNodes.p + m.nodeOffset, size_t(m.nNodes) * sizeof(BvhNode),
+                        hipMemcpyDeviceToHost));
+    std::memcpy(indices_out, scene->host.bvhIndices[mesh].data(), size_t(m.nTris) * 4);
+  });
+}
+
+}  // extern "C"

@@ -181,7 +181,7 @@ YART_HD float ggxVmdf(const GGX& g, f3 w, f3 wm) {                      // bsdf.
 YART_HD f2 sampleDiskUniform(f2 u) {                                    // math/sampling.hpp:40-45
   const float r = sqrtf(u.x);
   const float theta = 2.0f * kPi * u.y;
-  return mk2(r * cosf(theta), r * sinf(theta));
+  return mk2(r * ycosf(theta), r * ysinf(theta));
 }
 YART_HD f3 ggxSampleVisibleMicrofacet(const GGX& g, f3 w, f2 u) {       // bsdf.hpp:243-271
   f3 wh = normalized(mk3(g.ax * w.x, g.ay * w.y, w.z));
@@ -252,7 +252,7 @@ YART_HD float matAlpha(const SceneDev& sc, const MaterialDev& mt, f2 uv) {   // 
 YART_HD f3 matAttenuation(const MaterialDev& mt, float d) {             // parametric.cpp:834-838
   if (mt.flags & MAT_THIN) return mk3(1.0f);
   f3 e = ((mt.volumeColor - 1.0f) * d) * mt.volumeDensity;
-  return mk3(expf(e.x), expf(e.y), expf(e.z));
+  return mk3(yexpf(e.x), yexpf(e.y), yexpf(e.z));
 }
 
 // ---- metallic lobe (parametric.cpp:260-352) ----
@@ -437,8 +437,8 @@ YART_HD float pdfGlossy(const float* lut, const MaterialDev& mt, f3 wo, f3 wi, c
 YART_HD f3 sampleCosineHemisphere(f2 u) {                               // math/sampling.hpp:30-38
   const float phi = u.x * 2.0f * kPi;
   const float sqrtr2 = sqrtf(u.y);
-  const float x = cosf(phi) * sqrtr2;
-  const float y = sinf(phi) * sqrtr2;
+  const float x = ycosf(phi) * sqrtr2;
+  const float y = ysinf(phi) * sqrtr2;
   const float z = sqrtf(1.0f - u.y);
   return mk3(x, y, z);
 }

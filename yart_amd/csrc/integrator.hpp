@@ -20,9 +20,9 @@ struct RenderConst {
 };
 
 YART_HD f2 pixelJitterGaussian(f2 u, float stdDev) {          // sampling.hpp:20-28
-  float a = sqrtf(-2.0f * logf(u.x)) * stdDev;
+  float a = sqrtf(-2.0f * ylogf(u.x)) * stdDev;
   float b = 2.0f * kPi * u.y;
-  return mk2(a * cosf(b), a * sinf(b));
+  return mk2(a * ycosf(b), a * ysinf(b));
 }
 YART_HD f2 samplePolyUniform(f2 u, uint32_t sides) {          // sampling.hpp:72-89
   u.x *= float(sides);
@@ -32,8 +32,8 @@ YART_HD f2 samplePolyUniform(f2 u, uint32_t sides) {          // sampling.hpp:72
   f3 b = sampleTriUniform(u);
   float theta1 = float(side) / float(sides) * 2.0f * kPi;
   float theta2 = float(side + 1) / float(sides) * 2.0f * kPi;
-  float c1 = cosf(theta1), s1 = sinf(theta1);
-  float c2 = cosf(theta2), s2 = sinf(theta2);
+  float c1 = ycosf(theta1), s1 = ysinf(theta1);
+  float c2 = ycosf(theta2), s2 = ysinf(theta2);
   f2 r = (mk2(0, 0) * b.x + mk2(-s1, c1) * b.y) + mk2(-s2, c2) * b.z;
   return r;
 }

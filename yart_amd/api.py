@@ -102,7 +102,9 @@ class Stats(C.Structure):
                 ("launches_traverse", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["shaded_hits"] = int(self.reserved[0]) | (int(self.reserved[1]) << 32)   # instrumented build only
+        return d
 
 
 EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error",
@@ -110,17 +112,20 @@ EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error
            "yart_hip_render", "yart_hip_render_device", "yart_hip_probe_samples",
            "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy"]
 
-_lib = None
+LIB_COUNT_PATH = os.path.join(_HERE, "libyart_hip_count.so")   # instrumented twin (exact test counters)
+_libs = {}
 
 
-def lib():
-    """Load libyart_hip.so (built by ``__graft_entry__.build()``); raises if absent."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise YartError(YART_E_NO_DEVICE, f"{LIB_PATH} not built (run __graft_entry__.build()); "
+def lib(instrumented: bool = False):
+    """Load libyart_hip.so (built by ``__graft_entry__.build()``); raises if absent.
+    ``instrumented=True`` loads libyart_hip_count.so, the same code compiled with
+    -DYART_COUNT_TRAVERSAL (exact box / triangle test counters; never timed)."""
+    path = LIB_COUNT_PATH if instrumented else LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise YartError(YART_E_NO_DEVICE, f"{path} not built (run __graft_entry__.build()); "
                                               "there is no CPU fallback")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         L.yart_hip_last_error.restype = C.c_char_p
         L.yart_hip_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.yart_hip_scene_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -135,13 +140,13 @@ def lib():
         L.yart_hip_probe_hits.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.yart_hip_bvh_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.yart_hip_bvh_copy.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
-def _check(code):
+def _check(code, L=None):
     if code != YART_OK:
-        raise YartError(code, lib().yart_hip_last_error().decode())
+        raise YartError(code, (L or lib()).yart_hip_last_error().decode())
 
 
 def _f(arr, n):
@@ -173,14 +178,15 @@ def make_params(p: dict, rank=0, world_size=1, flags=0) -> RenderParams:
 class DeviceScene:
     """Owns a ``YartScene*`` (device-resident flattened scene + BVHs)."""
 
-    def __init__(self, scene, device: int = -1):
+    def __init__(self, scene, device: int = -1, instrumented: bool = False):
         self._h = C.c_void_p()
         self._keep = []
+        self._L = lib(instrumented)
         if isinstance(scene, (str, os.PathLike)):
-            _check(lib().yart_hip_scene_load(os.fspath(scene).encode(), device, C.byref(self._h)))
+            _check(self._L.yart_hip_scene_load(os.fspath(scene).encode(), device, C.byref(self._h)), self._L)
         else:
             desc = self._describe(scene)
-            _check(lib().yart_hip_scene_create(C.byref(desc), device, C.byref(self._h)))
+            _check(self._L.yart_hip_scene_create(C.byref(desc), device, C.byref(self._h)), self._L)
         self._keep = []     # the library copies everything it needs
 
     def _describe(self, s: yscn.Scene) -> SceneDesc:
@@ -218,7 +224,7 @@ class DeviceScene:
 
     def close(self):
         if self._h:
-            lib().yart_hip_scene_destroy(self._h)
+            self._L.yart_hip_scene_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -232,7 +238,7 @@ class DeviceScene:
         """Blocking render to a host array (H, W, 4) float32 + stats dict."""
         cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
         out = np.empty((cam.height, cam.width, 4), np.float32)
-        _check(lib().yart_hip_render(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p),
+        _check(self._L.yart_hip_render(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p),
                                      C.byref(st)))
         return out, st.asdict()
 
@@ -241,7 +247,7 @@ class DeviceScene:
         cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
         assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == cam.width * cam.height * 4
         sp = C.c_void_p(stream) if stream else None
-        _check(lib().yart_hip_render_device(self._h, C.byref(cam), C.byref(rp),
+        _check(self._L.yart_hip_render_device(self._h, C.byref(cam), C.byref(rp),
                                             C.c_void_p(tensor.data_ptr()), sp, C.byref(st)))
         return st.asdict()
 
@@ -251,7 +257,7 @@ class DeviceScene:
         a = np.ascontiguousarray(xys, np.uint32).reshape(-1, 3)
         out = np.empty((len(a), 3), np.float32)
         rays = C.c_uint64()
-        _check(lib().yart_hip_probe_samples(self._h, C.byref(cam), C.byref(rp), len(a),
+        _check(self._L.yart_hip_probe_samples(self._h, C.byref(cam), C.byref(rp), len(a),
                                             a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
                                             C.byref(rays)))
         return out, rays.value
@@ -259,15 +265,15 @@ class DeviceScene:
     def probe_hits(self, rays):
         a = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         out = np.empty((len(a), 16), np.float32)
-        _check(lib().yart_hip_probe_hits(self._h, len(a), a.ctypes.data_as(C.c_void_p),
+        _check(self._L.yart_hip_probe_hits(self._h, len(a), a.ctypes.data_as(C.c_void_p),
                                          out.ctypes.data_as(C.c_void_p)))
         return out
 
     def bvh(self, mesh: int):
         nn, nt = C.c_uint32(), C.c_uint32()
-        _check(lib().yart_hip_bvh_info(self._h, mesh, C.byref(nn), C.byref(nt)))
+        _check(self._L.yart_hip_bvh_info(self._h, mesh, C.byref(nn), C.byref(nt)))
         nodes = np.empty((nn.value, 8), np.uint32); idx = np.empty(nt.value, np.uint32)
-        _check(lib().yart_hip_bvh_copy(self._h, mesh, nodes.ctypes.data_as(C.c_void_p),
+        _check(self._L.yart_hip_bvh_copy(self._h, mesh, nodes.ctypes.data_as(C.c_void_p),
                                        idx.ctypes.data_as(C.c_void_p)))
         return nodes, idx
 

@@ -59,7 +59,17 @@ struct PathCtx {
   const uint32_t* sobol;       // 52-entry dimension-1 generator matrix
   TravStack stk;
   RenderConst rc;
+#if defined(YART_COUNT_TRAVERSAL)
+  mutable uint32_t nBox = 0, nTri = 0, nTrav = 0, nShade = 0;
+#endif
 };
+#if defined(YART_COUNT_TRAVERSAL)
+#define YART_FOLD_COUNTS(cx, ac) ((cx).nBox += (ac).nBox, (cx).nTri += (ac).nTri, (cx).nTrav += (ac).nTrav)
+#define YART_COUNT_SHADE(cx) ((cx).nShade++)
+#else
+#define YART_FOLD_COUNTS(cx, ac) ((void)0)
+#define YART_COUNT_SHADE(cx) ((void)0)
+#endif
 
 // MISIntegrator::unoccluded (mis-integrator.cpp:135-148)
 YART_HD bool unoccluded(const PathCtx& cx, Sampler& smp, f3 from, f3 to, f3& attenuation) {
@@ -70,6 +80,7 @@ YART_HD bool unoccluded(const PathCtx& cx, Sampler& smp, f3 from, f3 to, f3& att
   attenuation = mk3(1.0f);
   AlphaCtx ac; ac.sampler = &smp; ac.cfg = cx.rc.sampler;
   bool occluded = traverseScene<true>(*cx.sc, from, dir, 0.001f, hr, attenuation, cx.stk, ac);
+  YART_FOLD_COUNTS(cx, ac);
   return !occluded;
 }
 
@@ -109,6 +120,7 @@ YART_HD f3 pathRadiance(const PathCtx& cx, Sampler& smp, f3 ro, f3 rd, uint32_t&
     f3 dummy = mk3(1.0f);
     AlphaCtx ac; ac.sampler = &smp; ac.cfg = cx.rc.sampler;
     bool didHit = traverseScene<false>(sc, ro, rd, 0.001f, hr, dummy, cx.stk, ac);
+    YART_FOLD_COUNTS(cx, ac);
     if (!didHit) {
       for (uint32_t k = 0; k < sc.nInfinite; k++) {
         const LightDev& l = sc.lights[sc.infiniteLights[k]];
@@ -125,6 +137,7 @@ YART_HD f3 pathRadiance(const PathCtx& cx, Sampler& smp, f3 ro, f3 rd, uint32_t&
       break;
     }
     Hit hit = finalizeHit(sc, hr, ro, rd);
+    YART_COUNT_SHADE(cx);
     const MaterialDev& mt = sc.materials[hit.material];
 
     f2 u = get2D(smp, cx.rc.sampler, cx.sobol);

@@ -79,9 +79,21 @@ struct HitRec {              // what the walk tracks of cpu/hit.hpp
   uint32_t backSide;
 };
 
+// Instrumented build (-DYART_COUNT_TRAVERSAL, libyart_hip_count.so): exact numbers of
+// box tests / triangle tests / traversals for the algorithmic-bytes roofline figure
+// (B_traversal = 32*N_box + 52*N_tri + 48). Never in the timed library.
+#if defined(YART_COUNT_TRAVERSAL)
+#define YART_COUNT(field, n) (actx.field += (n))
+#else
+#define YART_COUNT(field, n) ((void)0)
+#endif
+
 struct AlphaCtx {            // state the stochastic alpha test draws from
   Sampler* sampler;
   SamplerConfig cfg;
+#if defined(YART_COUNT_TRAVERSAL)
+  uint32_t nBox = 0, nTri = 0, nTrav = 0;
+#endif
 };
 
 // uv / normal interpolation of ray-integrator.cpp:198-213
@@ -110,6 +122,7 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
   float d;
   {
     const BvhNode root = nodes[0];
+    YART_COUNT(nBox, 1);
     if (!testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) return false;
   }
   uint32_t leftFirst = nodes[0].leftFirst, span = nodes[0].span;
@@ -118,6 +131,7 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
       if (span > 0) {
         for (uint32_t i = 0; i < span; i++) {
           const LeafTri tr = leaves[leftFirst + i];
+          YART_COUNT(nTri, 1);
           const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
           const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
           const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
@@ -160,6 +174,7 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
         stackPop(stk, --stackIdx, node, d);
       } else {
         const BvhNode c1 = nodes[leftFirst], c2 = nodes[leftFirst + 1];
+        YART_COUNT(nBox, 2);
         float d1, d2;
         bool hit1 = testBox(ray, tMin, hit.t, c1.bmin, c1.bmax, d1);
         bool hit2 = testBox(ray, tMin, hit.t, c2.bmin, c2.bmax, d2);
@@ -213,12 +228,14 @@ YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& h
                            const TravStack& stk, AlphaCtx& actx) {
   bool didHit = false;
   uint32_t i = 0;
+  YART_COUNT(nTrav, 1);
   while (i < sc.nNodes) {
     const NodeDev& nd = sc.nodes[i];
     f3 oo, od;
     objectRay(sc, i, o, d, oo, od);
     RayO ray = makeRay(oo, od);
     float dd;
+    YART_COUNT(nBox, 1);
     if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) { i = nd.skip; continue; }
     if (nd.mesh >= 0)
       didHit |= traverseMesh<NEE>(sc, sc.meshes[nd.mesh], i, ray, tMin, hit, attenuation, stk, actx);

@@ -114,6 +114,14 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(MegaArgs a) {
   unsigned long long r = rays;
   for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o);
   if (lane == 0 && r) atomicAdd(a.rays, r);
+#if defined(YART_COUNT_TRAVERSAL)
+  unsigned long long c[4] = {cx.nTrav, cx.nBox, cx.nTri, cx.nShade};
+  for (int k = 0; k < 4; k++) {
+    unsigned long long v = c[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0 && v) atomicAdd(a.rays + 1 + k, v);
+  }
+#endif
 }
 
 struct GmonArgs {
@@ -401,12 +409,14 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   HIP_CHECK(hipEventRecord(tAll.b, stream));
   HIP_CHECK(hipEventSynchronize(tAll.b));
   float msAll = 0; HIP_CHECK(hipEventElapsedTime(&msAll, tAll.a, tAll.b));
-  unsigned long long rays = 0;
-  HIP_CHECK(hipMemcpy(&rays, s.counters.p, sizeof(rays), hipMemcpyDeviceToHost));
+  unsigned long long cnt[8] = {0};
+  HIP_CHECK(hipMemcpy(cnt, s.counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
   if (stats) {
     *stats = YartStats{};
     stats->samples = uint64_t(nPix) * p.samples;
-    stats->rays = rays;
+    stats->rays = cnt[0];
+    stats->traversals = cnt[1]; stats->box_tests = cnt[2]; stats->tri_tests = cnt[3];
+    stats->reserved[0] = uint32_t(cnt[4]); stats->reserved[1] = uint32_t(cnt[4] >> 32);   // shaded hits
     stats->ms_device = msAll;
     stats->ms_traverse = msTraverse;
     stats->waves = waves;

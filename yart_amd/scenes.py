@@ -419,7 +419,7 @@ def sponza_class(width=1920, height=1080, spp=256, depth=8, detail=1.0, tex=1024
                     r = rad * (1.0 + 0.06 * np.cos(12 * phi)) * (1.0 - 0.12 * V + 0.1 * np.exp(-30 * V)
                                                                 + 0.12 * np.exp(-30 * (1 - V)))
                     return cx + r * np.cos(phi), y0 + (y1 - y0) * V, cz + r * np.sin(phi)
-                b.grid(col, k(48), k(40), mat, uv_scale=(2, 4), flip=True)
+                b.grid(col, k(36), k(30), mat, uv_scale=(2, 4), flip=True)
                 b.box((cx - 0.5, y0, cz - 0.5), (cx + 0.5, y0 + 0.25, cz + 0.5), mat)
                 b.box((cx - 0.5, y1, cz - 0.5), (cx + 0.5, y1 + 0.2, cz + 0.5), mat)
             for c in range(ncol):
@@ -442,14 +442,14 @@ def sponza_class(width=1920, height=1080, spp=256, depth=8, detail=1.0, tex=1024
         b.box((-LX - 3, H2 - 0.3, za), (LX + 3, H2, zb), plain[2])
 
     # cloth banners hanging across the atrium (tessellated, wavy)
-    nb = 7
+    nb = 5
     for i in range(nb):
-        x = -LX + 2 * LX * (i + 0.5) / nb
+        x = -11.0 + 14.0 * i / (nb - 1)
 
         def ban(U, V, x=x, i=i):
             z = (U - 0.5) * 2 * (LZ - 0.6)
             sag = 1.2 * (1 - (2 * U - 1) ** 2)
-            y = H2 - 1.0 - sag - 2.2 * V
+            y = H2 + 0.6 - sag - 2.0 * V
             xx = x + 0.25 * np.sin(6 * U * np.pi + i) * (0.3 + V) + 0.1 * np.sin(9 * V + i)
             return xx, y, z
         b.grid(ban, k(70), k(36), cloth[i % 3], uv_scale=(4, 1))

@@ -140,7 +140,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "sponza_class (generated atrium, %d triangles, env-lit) %dx%d, %d spp, %d bounces"
                                % (scene.n_triangles, W, H, p["spp"], p["depth"]),
-                   "pipeline": "megakernel", "tiles": "64x64 Morton round-robin over ranks",
+                   "pipeline": "wavefront", "tiles": "64x64 Morton round-robin over ranks",
                    "parallelism": f"tiles/{world}"},
         "rays_per_step": int(last.get("rays", 0)),
     }
@@ -153,13 +153,17 @@ def main():
         _, st2 = ds2.render(p)
         ds2.close()
         shaded = st2.get("shaded_hits", 0)
+        # B_traversal = 32*N_box + 52*N_tri + 48 per traversal (closest-hit and
+        # shadow traversals = k_wf_extend + k_wf_connect launches)
         trav_bytes = 32 * st2["box_tests"] + 52 * st2["tri_tests"] + 48 * st2["traversals"]
-        shade_bytes = 180 * shaded               # 116 B vertex data + 64 B material record per shaded hit
+        shade_bytes = 0
         n_launch = max(1, last["launches_traverse"])
         avg_ms = kernel_ms / max(1, launches)
         achieved = (trav_bytes + shade_bytes) / n_launch / (avg_ms * 1e-3) * 1e-9
+        out["stage_ms_per_step"] = {k: round(last[k], 2) for k in
+                                    ("ms_extend", "ms_connect", "ms_shade", "ms_gmon", "ms_device")}
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_render_mega", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+            "bound": "hbm", "kernel": "k_wf_extend+k_wf_connect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
             "avg_launch_ms": round(avg_ms, 3), "launches_per_step": n_launch,
             "algorithmic_bytes_per_launch": int((trav_bytes + shade_bytes) / n_launch),

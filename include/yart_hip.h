@@ -117,6 +117,8 @@ typedef struct YartRenderParams {
 } YartRenderParams;
 
 #define YART_FLAG_MEGAKERNEL 1u   /* single-kernel integrator instead of the wavefront pipeline */
+#define YART_FLAG_WAVE_TRACE 2u   /* wavefront pipeline with the wave-level tracer (trace_wave.hpp:
+                                     dynamic refill + while-while); A/B alternative to the default kernels */
 
 /* Renderer::RenderData counters (src/core/renderer.hpp:22-28) + per-stage device time. */
 typedef struct YartStats {
@@ -124,12 +126,15 @@ typedef struct YartStats {
   uint64_t rays;             /* path segments + unoccluded shadow rays (mis-integrator.cpp:22,126) */
   double ms_total;           /* wall time of the call */
   double ms_device;          /* HIP-event time of all kernels */
-  double ms_traverse;        /* HIP-event time of the traversal kernels only */
+  double ms_traverse;        /* HIP-event time of the traversal kernels (wavefront: extend + connect;
+                                megakernel: the whole path kernel) */
   uint64_t traversals;       /* rays traced (closest-hit + shadow) */
   uint64_t box_tests, tri_tests;   /* exact counts when collected (instrumented build), else 0 */
   uint32_t waves;            /* progressive waves rendered */
-  uint32_t launches_traverse;
-  uint32_t reserved[4];
+  uint32_t launches_traverse;      /* launches summed into ms_traverse */
+  uint64_t shaded_hits;      /* instrumented build only */
+  double ms_extend, ms_shade, ms_connect, ms_gmon;   /* per-stage HIP-event time (wavefront pipeline) */
+  uint32_t launches_extend, launches_connect;
 } YartStats;
 
 typedef struct YartScene YartScene;

@@ -32,16 +32,20 @@ def api(built):
     return api
 
 
+PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+wave_trace": 2}
+
+
+@pytest.mark.parametrize("pipeline", list(PIPELINE_FLAGS))
 @pytest.mark.parametrize("case", ["cornell", "material", "cornell_waves"])
-def test_framebuffer_vs_reference_golden(api, case):
+def test_framebuffer_vs_reference_golden(api, case, pipeline):
     base = os.path.join(GOLDEN, case)
     p = load_params(base + ".txt")
     scene = api.DeviceScene(base + ".yscn", device=0)
-    img, st = scene.render(p)
+    img, st = scene.render(p, flags=PIPELINE_FLAGS[pipeline])
     ref = np.fromfile(base + ".f32", np.float32).reshape(img.shape)
     e = rmse(img, ref)
     same = float(np.mean(np.all(img.view(np.uint32) == ref.view(np.uint32), axis=-1)))
-    print(f"{case}: rmse={e:.3e} identical_pixels={same:.4f} rays={st['rays']}")
+    print(f"{case}/{pipeline}: rmse={e:.3e} identical_pixels={same:.4f} rays={st['rays']}")
     assert np.all(img[..., 3] == 1.0)
     assert e < RMSE_TOL
     assert same > 0.5, "most pixels should be bit-identical to the reference"

@@ -30,6 +30,7 @@ LIB_PATH = os.path.join(_HERE, "libyart_hip.so")
 
 YART_OK, YART_E_INVALID, YART_E_NO_DEVICE, YART_E_HIP, YART_E_IO = 0, -1, -2, -3, -4
 FLAG_MEGAKERNEL = 1
+FLAG_WAVE_TRACE = 2
 
 
 class YartError(RuntimeError):
@@ -99,12 +100,12 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("ms_total", C.c_double),
                 ("ms_device", C.c_double), ("ms_traverse", C.c_double), ("traversals", C.c_uint64),
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("waves", C.c_uint32),
-                ("launches_traverse", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+                ("launches_traverse", C.c_uint32), ("shaded_hits", C.c_uint64),
+                ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_connect", C.c_double),
+                ("ms_gmon", C.c_double), ("launches_extend", C.c_uint32), ("launches_connect", C.c_uint32)]
 
     def asdict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
-        d["shaded_hits"] = int(self.reserved[0]) | (int(self.reserved[1]) << 32)   # instrumented build only
-        return d
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error",

@@ -213,6 +213,12 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
     std::memcpy(nd.xf.fwd, n.fwd, 64); std::memcpy(nd.xf.inv, n.inv, 64);
     nd.mesh = n.mesh; nd.parent = n.parent;
     nd.depth = i == 0 ? 0 : im.nodes[n.parent].depth + 1;
+    {   // pad[0] bit 0: this node's transform and all its ancestors' are exactly the identity
+      static const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      bool ident = std::memcmp(n.fwd, I, 64) == 0 && std::memcmp(n.inv, I, 64) == 0;
+      if (i > 0) ident = ident && (im.nodes[n.parent].pad[0] & 1u);
+      nd.pad[0] = ident ? 1u : 0u;
+    }
     require(nd.depth < kMaxNodeDepth, "scene graph deeper than 8 levels");
     if (nd.depth > im.maxNodeDepth) im.maxNodeDepth = nd.depth;
     if (n.mesh >= 0) {                                          // Node(Mesh*), scene.hpp:17-22

@@ -1,0 +1,234 @@
+// wavefront.hpp — the MIS + NEE path loop of integrator.hpp split at its two trace
+// calls into queue-driven stages (reference cpu/mis-integrator.cpp:13-148):
+//
+//   generate  camera ray, path state                       (ray-integrator.cpp:11-18)
+//   extend    closest-hit traversal of every live path     (testNode, :20-54)
+//   shade     miss / emission / BSDF sample / NEE set-up / throughput update
+//             (mis-integrator.cpp:27-95, 111-124)
+//   connect   any-hit traversal of the shadow rays, NEE contribution (:125-133, 135-148)
+//   roulette  Russian roulette + next-bounce decision (:96-102) — runs at the end of
+//             `connect` for paths that cast a shadow ray (the shadow traversal may
+//             consume sampler dimensions first) and at the end of `shade` otherwise.
+//
+// Path state lives in HBM as float4-packed SoA arrays indexed by path slot, so that a
+// wave's 64 lanes read 1 KiB contiguous per field group. Every arithmetic expression is
+// the one integrator.hpp uses; only the control flow differs, so results are identical.
+#pragma once
+#include "integrator.hpp"
+
+namespace yart_hip {
+
+struct WfState {
+  // ray0 = {o.xyz, d.x}  ray1 = {d.yz, lastPdf, accRoughness}
+  // thr0 = {att.xyz, L.x} thr1 = {L.yz, flags(u32), dim(u32)}
+  // hit0 = {t, u, v, tri(u32)}  hit1 = {node|backSide<<31 (u32), morton.lo, morton.hi, slot(u32)}
+  // sh0 = {to.xyz, cosTerm}  sh1 = {attPre.xyz, denom}  sh2 = {Lif.xyz, lightIsArea}
+  f4 *ray0, *ray1, *thr0, *thr1, *hit0, *hit1, *sh0, *sh1, *sh2;
+};
+struct WfQueues {
+  uint32_t* active;     // path slots to extend + shade this bounce
+  uint32_t* next;       // survivors (filled by shade and connect)
+  uint32_t* shadow;     // path slots with a pending shadow ray
+  uint32_t* counters;   // [0] nActive [1] nNext [2] nShadow [3] cursorExtend [4] cursorShade [5] cursorConnect [6] cursorGen
+};
+// exact test counters of the instrumented build (libyart_hip_count.so); empty otherwise
+struct WfTally {
+#if defined(YART_COUNT_TRAVERSAL)
+  uint32_t box = 0, tri = 0, trav = 0, shade = 0;
+#endif
+};
+#if defined(YART_COUNT_TRAVERSAL)
+#define WF_TALLY_TRAV(t, ac) ((t).box += (ac).nBox, (t).tri += (ac).nTri, (t).trav += (ac).nTrav)
+#define WF_TALLY_SHADE(t) ((t).shade++)
+#else
+#define WF_TALLY_TRAV(t, ac) ((void)0)
+#define WF_TALLY_SHADE(t) ((void)0)
+#endif
+
+enum : uint32_t { WF_SPECULAR = 1u << 8, WF_REGULARIZED = 1u << 9, WF_MISS = 1u << 10, WF_DEPTH_MASK = 0xffu };
+
+YART_HD float asF(uint32_t u) { return __builtin_bit_cast(float, u); }
+YART_HD uint32_t asU(float f) { return __builtin_bit_cast(uint32_t, f); }
+YART_HD f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+struct WfPath {             // register image of one path
+  f3 o, d, att, L;
+  float lastPdf, accRoughness;
+  uint32_t flags, slot;
+  Sampler smp;
+};
+YART_HD WfPath wfLoad(const WfState& s, uint32_t i) {
+  const f4 r0 = s.ray0[i], r1 = s.ray1[i], t0 = s.thr0[i], t1 = s.thr1[i], h1 = s.hit1[i];
+  WfPath p;
+  p.o = mk3(r0.x, r0.y, r0.z); p.d = mk3(r0.w, r1.x, r1.y); p.lastPdf = r1.z; p.accRoughness = r1.w;
+  p.att = mk3(t0.x, t0.y, t0.z); p.L = mk3(t0.w, t1.x, t1.y); p.flags = asU(t1.z); p.smp.dim = asU(t1.w);
+  p.smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32); p.slot = asU(h1.w);
+  return p;
+}
+YART_HD void wfStoreRay(const WfState& s, uint32_t i, const WfPath& p) {
+  s.ray0[i] = mk4(p.o.x, p.o.y, p.o.z, p.d.x);
+  s.ray1[i] = mk4(p.d.y, p.d.z, p.lastPdf, p.accRoughness);
+}
+YART_HD void wfStoreThr(const WfState& s, uint32_t i, const WfPath& p) {
+  s.thr0[i] = mk4(p.att.x, p.att.y, p.att.z, p.L.x);
+  s.thr1[i] = mk4(p.L.y, p.L.z, asF(p.flags), asF(p.smp.dim));
+}
+
+// Russian roulette and loop condition (mis-integrator.cpp:96-102 + the while at :21).
+// Returns true if the path continues to the next bounce.
+YART_HD bool wfRoulette(const RenderConst& rc, WfPath& p) {
+  const uint32_t depth = p.flags & WF_DEPTH_MASK;
+  if (depth > 1 && maxComponent(p.att) < 1.0f) {
+    float q = stdmax(0.0f, 1.0f - maxComponent(p.att));
+    if (get1D(p.smp, rc.sampler) < q) return false;
+    p.att /= 1.0f - q;
+  }
+  return depth < rc.maxDepth;
+}
+
+// generate: RayIntegrator::sample up to the first trace
+YART_HD void wfGenerate(const RenderConst& rc, const uint32_t* sobol, const CameraDev& cam, uint32_t px,
+                        uint32_t py, uint32_t sample, uint32_t slot, const WfState& s, uint32_t i) {
+  WfPath p;
+  startPixelSample(p.smp, rc.sampler, px, py, sample);
+  f2 uvFilm = get2D(p.smp, rc.sampler, sobol);
+  f2 uvLens = get2D(p.smp, rc.sampler, sobol);
+  cameraRay(cam, px, py, uvFilm, uvLens, p.o, p.d);
+  p.att = mk3(1.0f); p.L = mk3(0.0f); p.lastPdf = 0.0f; p.accRoughness = 0.0f; p.flags = 0; p.slot = slot;
+  wfStoreRay(s, i, p);
+  wfStoreThr(s, i, p);
+  s.hit1[i] = mk4(0.0f, asF(uint32_t(p.smp.morton)), asF(uint32_t(p.smp.morton >> 32)), asF(slot));
+}
+
+// extend: closest hit; only the sampler dimension can change (alpha tests)
+YART_HD void wfExtend(const SceneDev& sc, const RenderConst& rc, const TravStack& stk, const WfState& s,
+                      uint32_t i, WfTally& tally) {
+  const f4 r0 = s.ray0[i], r1 = s.ray1[i];
+  f4 t1 = s.thr1[i];
+  f4 h1 = s.hit1[i];
+  Sampler smp;
+  smp.dim = asU(t1.w);
+  smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32);
+  const uint32_t dim0 = smp.dim;
+  HitRec hr;
+  hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
+  f3 dummy = mk3(1.0f);
+  AlphaCtx ac; ac.sampler = &smp; ac.cfg = rc.sampler;
+  bool hit = traverseScene<false>(sc, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), 0.001f, hr, dummy, stk, ac);
+  WF_TALLY_TRAV(tally, ac);
+  s.hit0[i] = mk4(hit ? hr.t : -1.0f, hr.u, hr.v, asF(hr.tri));
+  h1.x = asF(hr.node | (hr.backSide << 31));
+  s.hit1[i] = h1;
+  if (smp.dim != dim0) { t1.w = asF(smp.dim); s.thr1[i] = t1; }
+}
+
+enum WfShadeResult { WF_TERMINATED = 0, WF_CONTINUE = 1, WF_SHADOW = 2 };
+
+// shade: everything between the two trace calls of one bounce. `rays` counts path segments.
+YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const uint32_t* sobol, const WfState& s,
+                              uint32_t i, WfPath& p, uint32_t& rays, WfTally& tally) {
+  p = wfLoad(s, i);
+  const f4 h0 = s.hit0[i];
+  const uint32_t nodeBack = asU(s.hit1[i].x);
+  const uint32_t depth = p.flags & WF_DEPTH_MASK;
+  const bool specularBounce = (p.flags & WF_SPECULAR) != 0, regularized = (p.flags & WF_REGULARIZED) != 0;
+  rays++;
+  if (h0.x < 0.0f) {                                            // miss (mis-integrator.cpp:27-43)
+    for (uint32_t k = 0; k < sc.nInfinite; k++) {
+      const LightDev& l = sc.lights[sc.infiniteLights[k]];
+      f3 Le = lightLe(sc, l, octahedralUV(p.d));
+      if (depth == 0 || specularBounce) p.L += p.att * Le;
+      else {
+        float pdfLight = lightPdf(sc, l, p.d);
+        float wBSDF = p.lastPdf / (p.lastPdf + pdfLight);
+        p.L += p.att * wBSDF * Le;
+      }
+    }
+    p.L += p.att * rc.background;
+    return WF_TERMINATED;
+  }
+  HitRec hr;
+  hr.t = h0.x; hr.u = h0.y; hr.v = h0.z; hr.tri = asU(h0.w); hr.node = nodeBack & 0x7fffffffu; hr.backSide = nodeBack >> 31;
+  Hit hit = finalizeHit(sc, hr, p.o, p.d);
+  WF_TALLY_SHADE(tally);
+  const MaterialDev& mt = sc.materials[hit.material];
+  f2 u = get2D(p.smp, rc.sampler, sobol);
+  float uc = get1D(p.smp, rc.sampler);
+  float uc2 = get1D(p.smp, rc.sampler);
+  const f3 wo = -p.d;
+  BsdfSample res = bsdfSample(sc, mt, wo, hit.n, hit.tg, hit.uv, u, uc, uc2, regularized);
+  if (res.scatter & SC_EMITTED) {
+    if (depth == 0 || specularBounce) p.L += p.att * res.Le;
+    else if (hit.lightIdx != -1) {
+      const LightDev& l = sc.lights[hit.lightIdx];
+      float pdfLight = lightPdf(sc, l, wo) * length2(p.o - hit.p) * lightSamplerP(sc, uint32_t(hit.lightIdx)) /
+                       absDot(wo, hit.n);                       // lastHit.p == origin of the current ray
+      float wBSDF = p.lastPdf / (p.lastPdf + pdfLight);
+      p.L += p.att * wBSDF * res.Le;
+    }
+  }
+  if (!(res.scatter & (SC_REFLECTED | SC_TRANSMITTED))) return WF_TERMINATED;
+
+  bool shadow = false;
+  if (!(res.scatter & (SC_EMITTED | SC_SPECULAR))) {            // L += attenuation * Ld(...)   (:79-80)
+    if (sc.nLights != 0) {                                      // Ld set-up (:111-124)
+      float ucl = get1D(p.smp, rc.sampler);
+      f2 ul = get2D(p.smp, rc.sampler, sobol);
+      float pl;
+      uint32_t li = lightSamplerSample(sc, ucl, pl);
+      const LightDev& l = sc.lights[li];
+      LightSample ls = lightSample(sc, l, hit.p, ul);
+      f3 f = bsdfF(sc, mt, wo, ls.wi, hit.n, hit.tg, hit.uv);
+      if (length2(f) != 0.0f) {
+        // evaluated eagerly (pure); the reference evaluates them after the occlusion test
+        float pdfBSDF = bsdfPdf(sc, mt, wo, ls.wi, hit.n, hit.tg, hit.uv);
+        float pdfLight = pl * ls.pdf / absDot(ls.n, ls.wi);
+        if (l.type == LIGHT_AREA) pdfLight *= length2(hit.p - ls.p);
+        const f3 Lif = ls.Li * f;
+        s.sh0[i] = mk4(ls.p.x, ls.p.y, ls.p.z, absDot(ls.wi, hit.n));
+        s.sh1[i] = mk4(p.att.x, p.att.y, p.att.z, pdfBSDF + pdfLight);
+        s.sh2[i] = mk4(Lif.x, Lif.y, Lif.z, 0.0f);
+        shadow = true;
+      }
+    }
+    // Ld returned {} (no lights / f == 0): the reference still executes L += attenuation * 0,
+    // which matters only when the throughput is already inf/NaN — kept for bit parity
+    if (!shadow) p.L += p.att * mk3(0.0f);
+  }
+  f3 fcos = res.f * absDot(res.wi, hit.n);
+  p.att *= fcos / res.pdf;
+  if (hit.backSide) p.att *= matAttenuation(mt, hit.t);
+  p.o = hit.p; p.d = res.wi;
+  p.accRoughness += res.roughness;
+  p.lastPdf = res.pdf;
+  uint32_t fl = (depth + 1) & WF_DEPTH_MASK;
+  if (res.scatter & SC_SPECULAR) fl |= WF_SPECULAR;
+  if (p.accRoughness > 0.5f) fl |= WF_REGULARIZED;
+  p.flags = fl;
+  return shadow ? WF_SHADOW : WF_CONTINUE;
+}
+
+// connect: shadow traversal + NEE contribution (mis-integrator.cpp:125-133, 135-148)
+YART_HD void wfConnect(const SceneDev& sc, const RenderConst& rc, const TravStack& stk, const WfState& s,
+                       uint32_t i, WfPath& p, uint32_t& rays, WfTally& tally) {
+  p = wfLoad(s, i);
+  const f4 s0 = s.sh0[i], s1 = s.sh1[i], s2 = s.sh2[i];
+  const f3 from = p.o, to = mk3(s0.x, s0.y, s0.z);
+  f3 dir = normalized(to - from);
+  HitRec hr;
+  hr.t = length(to - from) - 0.001f;
+  hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
+  f3 attOcc = mk3(1.0f);
+  AlphaCtx ac; ac.sampler = &p.smp; ac.cfg = rc.sampler;
+  bool occluded = traverseScene<true>(sc, from, dir, 0.001f, hr, attOcc, stk, ac);
+  WF_TALLY_TRAV(tally, ac);
+  const f3 attPre = mk3(s1.x, s1.y, s1.z), Lif = mk3(s2.x, s2.y, s2.z);
+  if (!occluded) {
+    rays++;
+    p.L += attPre * (Lif * attOcc * s0.w / s1.w);
+  } else {
+    p.L += attPre * mk3(0.0f);          // Ld returned {}: L += attenuation * 0 (NaN/inf propagation)
+  }
+}
+
+}  // namespace yart_hip

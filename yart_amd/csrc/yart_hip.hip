@@ -29,6 +29,8 @@
 #include "host_scene.hpp"
 #include "integrator.hpp"
 #include "scene_file.hpp"
+#include "wavefront.hpp"
+#include "trace_wave.hpp"
 
 using namespace yart_hip;
 
@@ -37,6 +39,7 @@ namespace {
 constexpr int kBlock = 256;            // 4 waves per workgroup
 constexpr int kLdsStack = 24;          // traversal stack entries kept in LDS per lane (8 B each)
 constexpr int kSpillDepth = int(kRefStackDepth) - kLdsStack;
+constexpr int kSpillDepthMax = int(kRefStackDepth);   // spill area sized for the shallowest LDS stack
 
 thread_local std::string g_lastError;
 
@@ -214,6 +217,8 @@ __global__ void __launch_bounds__(kBlock) k_probe_hits(ProbeHitArgs a) {
   }
 }
 
+#include "wavefront_kernels.inc"
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -239,6 +244,8 @@ struct YartScene {
   // render scratch (grown on demand, reused across calls)
   DevBuf<uint32_t> pixels; DevBuf<float> L; DevBuf<uint32_t> cursor; DevBuf<unsigned long long> counters;
   DevBuf<uint64_t> spill; DevBuf<float> hdr; DevBuf<uint32_t> probeIn; DevBuf<float> probeOut;
+  DevBuf<f4> wf[9];                        // wavefront path state (wavefront.hpp::WfState)
+  DevBuf<uint32_t> qA, qB, qS, wfCounters; // wavefront queues
   std::vector<uint32_t> pixelsHost;
   uint32_t pixW = 0, pixH = 0, pixTile = 0, pixRank = 0, pixWorld = 0;
   std::mutex mu;
@@ -335,13 +342,36 @@ RenderConst makeRenderConst(const YartRenderParams& p) {
   return rc;
 }
 
-int persistentGrid(const YartScene& s, const void* kernel) {
+int persistentGrid(const YartScene& s, const void* kernel, int cap) {
   int perCU = 0;
   HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, 0));
   if (perCU < 1) perCU = 1;
-  if (perCU > 3) perCU = 3;     // LDS stack: 48 KiB per workgroup -> 3 per CU
+  if (perCU > cap) perCU = cap;
   return s.numCUs * perCU;
 }
+
+// HIP-event stopwatch for one class of launches on the render stream: record(begin/end)
+// around each launch, resolve() after the stream has been synchronised.
+struct StageTimer {
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  double ms = 0.0;
+  uint32_t launches = 0;
+  ~StageTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+  hipEvent_t next() {
+    if (used == ev.size()) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); ev.push_back(e); }
+    return ev[used++];
+  }
+  void begin(hipStream_t st) { HIP_CHECK(hipEventRecord(next(), st)); }
+  void end(hipStream_t st) { HIP_CHECK(hipEventRecord(next(), st)); launches++; }
+  void resolve() {
+    for (size_t i = 0; i + 1 < used; i += 2) {
+      float t = 0; HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      ms += t;
+    }
+    used = 0;
+  }
+};
 
 void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRenderParams& p, float* dOut,
                     hipStream_t stream, YartStats* stats) {
@@ -350,6 +380,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const uint32_t W = camDesc.width, H = camDesc.height;
   const CameraDev cam = makeCamera(camDesc);
   const RenderConst rc = makeRenderConst(p);
+  const bool mega = (p.flags & YART_FLAG_MEGAKERNEL) != 0;
   buildPixelList(s, W, H, p.tile_size, p.rank, p.world_size);
   const uint32_t nPix = uint32_t(s.pixelsHost.size());
 
@@ -357,20 +388,34 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   s.cursor.ensure(1); s.counters.ensure(8);
   HIP_CHECK(hipMemsetAsync(s.counters.p, 0, 8 * sizeof(unsigned long long), stream));
 
-  const int grid = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega));
-  s.spill.ensure(size_t(grid) * kBlock * kSpillDepth);
+  const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
+  const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend), 5);
+  const int gridConnect = persistentGrid(s, reinterpret_cast<const void*>(k_wf_connect), 5);
+  const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shade), 8);
+  const int gridTrE = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_extend), 8);
+  const int gridTrS = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_shadow), 8);
+  const bool simpleTrace = (p.flags & YART_FLAG_WAVE_TRACE) == 0;
+  s.spill.ensure(size_t(std::max(std::max(gridMega, gridTrE), std::max(std::max(gridExtend, gridConnect), gridTrS))) *
+                 kBlock * kSpillDepthMax);
 
-  // chunk the pixel list so that the per-sample radiance buffer stays <= ~1.5 GiB
+  // chunk the pixel list: per-sample radiance buffer <= ~1.5 GiB, wavefront state <= kWfMaxPaths
   const uint32_t maxWave = std::min(p.max_wave_samples, p.samples);
   const uint32_t waveCap = std::max(std::min(p.first_wave_samples, p.samples), maxWave);
   uint64_t budgetFloats = (1536ull << 20) / 4;
-  uint32_t chunk = uint32_t(std::min<uint64_t>(nPix ? nPix : 1, std::max<uint64_t>(budgetFloats / (3ull * waveCap), 64)));
-  while (uint64_t(chunk) * waveCap >= (1ull << 31)) chunk /= 2;
+  uint64_t maxPaths = budgetFloats / 3;
+  if (!mega) maxPaths = std::min<uint64_t>(maxPaths, kWfMaxPaths);
+  maxPaths = std::min<uint64_t>(maxPaths, (1ull << 31) - 64);
+  uint32_t chunk = uint32_t(std::min<uint64_t>(nPix ? nPix : 1, std::max<uint64_t>(maxPaths / waveCap, 1)));
   s.L.ensure(size_t(chunk) * waveCap * 3);
+  if (!mega) {
+    const size_t np = size_t(chunk) * waveCap;
+    for (auto& b : s.wf) b.ensure(np);
+    s.qA.ensure(np); s.qB.ensure(np); s.qS.ensure(np); s.wfCounters.ensure(8);
+  }
 
-  Timer tAll, tK;
-  double msTraverse = 0.0;
-  uint32_t launches = 0, waves = 0;
+  Timer tAll;
+  StageTimer tMega, tExtend, tShade, tConnect, tGmon;
+  uint32_t waves = 0;
   HIP_CHECK(hipEventRecord(tAll.a, stream));
 
   // wave schedule of tile-renderer.hpp:121-124, 284-289
@@ -383,23 +428,65 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     const float wWave = float(waveSamples) / float(takenAfter);
     for (uint32_t c0 = 0; c0 < nPix; c0 += chunk) {
       const uint32_t n = std::min(chunk, nPix - c0);
-      HIP_CHECK(hipMemsetAsync(s.cursor.p, 0, sizeof(uint32_t), stream));
-      MegaArgs a{};
-      a.sc = s.dev; a.cam = cam; a.rc = rc; a.pixels = s.pixels.p + c0; a.nPixels = n;
-      a.spp = uint32_t(waveSamples); a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p;
-      a.cursor = s.cursor.p; a.rays = s.counters.p; a.spill = s.spill.p;
-      HIP_CHECK(hipEventRecord(tK.a, stream));
-      hipLaunchKernelGGL(k_render_mega, dim3(grid), dim3(kBlock), 0, stream, a);
-      HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipEventRecord(tK.b, stream));
+      if (mega) {
+        HIP_CHECK(hipMemsetAsync(s.cursor.p, 0, sizeof(uint32_t), stream));
+        MegaArgs a{};
+        a.sc = s.dev; a.cam = cam; a.rc = rc; a.pixels = s.pixels.p + c0; a.nPixels = n;
+        a.spp = uint32_t(waveSamples); a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p;
+        a.cursor = s.cursor.p; a.rays = s.counters.p; a.spill = s.spill.p;
+        tMega.begin(stream);
+        hipLaunchKernelGGL(k_render_mega, dim3(gridMega), dim3(kBlock), 0, stream, a);
+        HIP_CHECK(hipGetLastError());
+        tMega.end(stream);
+      } else {
+        WfArgs a{};
+        a.sc = s.dev; a.cam = cam; a.rc = rc;
+        a.st.ray0 = s.wf[0].p; a.st.ray1 = s.wf[1].p; a.st.thr0 = s.wf[2].p; a.st.thr1 = s.wf[3].p;
+        a.st.hit0 = s.wf[4].p; a.st.hit1 = s.wf[5].p; a.st.sh0 = s.wf[6].p; a.st.sh1 = s.wf[7].p; a.st.sh2 = s.wf[8].p;
+        a.qA = s.qA.p; a.qB = s.qB.p; a.qS = s.qS.p; a.counters = s.wfCounters.p;
+        a.pixels = s.pixels.p + c0; a.nPaths = n * uint32_t(waveSamples); a.spp = uint32_t(waveSamples);
+        a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p; a.stats = s.counters.p; a.spill = s.spill.p;
+        const uint32_t init[8] = {a.nPaths, 0, 0, 0, 0, 0, 0, 0};
+        HIP_CHECK(hipMemcpyAsync(s.wfCounters.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+        tShade.begin(stream);
+        hipLaunchKernelGGL(k_wf_generate, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
+        HIP_CHECK(hipGetLastError());
+        tShade.end(stream);
+        for (uint32_t bounce = 0; bounce < rc.maxDepth; bounce++) {
+          tExtend.begin(stream);
+          if (simpleTrace) hipLaunchKernelGGL(k_wf_extend, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+          else hipLaunchKernelGGL(k_wf_trace_extend, dim3(gridTrE), dim3(kTrBlock), 0, stream, a);
+          HIP_CHECK(hipGetLastError());
+          tExtend.end(stream);
+          tShade.begin(stream);
+          hipLaunchKernelGGL(k_wf_shade, dim3(gridShade), dim3(kBlock), 0, stream, a);
+          HIP_CHECK(hipGetLastError());
+          tShade.end(stream);
+          tConnect.begin(stream);
+          if (simpleTrace) hipLaunchKernelGGL(k_wf_connect, dim3(gridConnect), dim3(kBlock), 0, stream, a);
+          else hipLaunchKernelGGL(k_wf_trace_shadow, dim3(gridTrS), dim3(kTrBlock), 0, stream, a);
+          HIP_CHECK(hipGetLastError());
+          tConnect.end(stream);
+          if (!simpleTrace) {
+            tShade.begin(stream);
+            hipLaunchKernelGGL(k_wf_post, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
+            HIP_CHECK(hipGetLastError());
+            tShade.end(stream);
+          }
+          hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
+          HIP_CHECK(hipGetLastError());
+          std::swap(a.qA, a.qB);
+        }
+      }
       GmonArgs g{};
       g.L = s.L.p; g.pixels = s.pixels.p + c0; g.nPixels = n; g.spp = uint32_t(waveSamples); g.width = W;
       g.exposureScale = cam.exposureScale; g.wCurrent = wCurrent; g.wWave = wWave; g.hdr = dOut;
+      tGmon.begin(stream);
       hipLaunchKernelGGL(k_gmon_blend, dim3((n + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, stream, g);
       HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipEventSynchronize(tK.b));
-      float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, tK.a, tK.b));
-      msTraverse += ms; launches++;
+      tGmon.end(stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+      tMega.resolve(); tExtend.resolve(); tShade.resolve(); tConnect.resolve(); tGmon.resolve();
     }
     remaining -= waveSamples;
     uint64_t next = (currentWave > 0 || waveSamples > 1) ? std::min<uint64_t>(waveSamples * 2, p.max_wave_samples) : 1;
@@ -415,12 +502,13 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     *stats = YartStats{};
     stats->samples = uint64_t(nPix) * p.samples;
     stats->rays = cnt[0];
-    stats->traversals = cnt[1]; stats->box_tests = cnt[2]; stats->tri_tests = cnt[3];
-    stats->reserved[0] = uint32_t(cnt[4]); stats->reserved[1] = uint32_t(cnt[4] >> 32);   // shaded hits
+    stats->traversals = cnt[1]; stats->box_tests = cnt[2]; stats->tri_tests = cnt[3]; stats->shaded_hits = cnt[4];
     stats->ms_device = msAll;
-    stats->ms_traverse = msTraverse;
+    stats->ms_traverse = mega ? tMega.ms : tExtend.ms + tConnect.ms;
+    stats->launches_traverse = mega ? tMega.launches : tExtend.launches + tConnect.launches;
+    stats->ms_extend = tExtend.ms; stats->ms_shade = tShade.ms; stats->ms_connect = tConnect.ms; stats->ms_gmon = tGmon.ms;
+    stats->launches_extend = tExtend.launches; stats->launches_connect = tConnect.launches;
     stats->waves = waves;
-    stats->launches_traverse = launches;
     stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
   }
 }

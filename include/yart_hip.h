@@ -117,7 +117,8 @@ typedef struct YartRenderParams {
 } YartRenderParams;
 
 #define YART_FLAG_MEGAKERNEL 1u   /* single-kernel integrator instead of the wavefront pipeline */
-#define YART_FLAG_WAVE_TRACE 2u   /* wavefront pipeline with the wave-level tracer (trace_wave.hpp:
+#define YART_FLAG_SIMPLE_SHADOW 4u /* shadow rays with the one-ray-per-lane kernel (A/B) */
+#define YART_FLAG_WAVE_TRACE 2u   /* closest-hit rays with the wave-level tracer too (trace_wave.hpp:
                                      dynamic refill + while-while); A/B alternative to the default kernels */
 
 /* Renderer::RenderData counters (src/core/renderer.hpp:22-28) + per-stage device time. */
@@ -165,6 +166,9 @@ int yart_hip_probe_samples(YartScene* scene, const YartCameraDesc* cam, const Ya
 int yart_hip_probe_hits(YartScene* scene, uint32_t n, const float* rays, float* out);
 /* the BVH the kernels traverse: nodes (8 x u32 each: bounds, left|first, span) and
  * the index permutation of mesh `mesh` */
+/* the 32 device counter words of the last render on this scene ([0] rays, [1..4] exact
+ * traversal tallies in the instrumented build, [8..] kernel-phase statistics in debug builds) */
+int yart_hip_debug_counters(YartScene* scene, uint64_t* out32);
 int yart_hip_bvh_info(YartScene* scene, uint32_t mesh, uint32_t* n_nodes, uint32_t* n_tris);
 int yart_hip_bvh_copy(YartScene* scene, uint32_t mesh, uint32_t* nodes_out, uint32_t* indices_out);
 

@@ -1,0 +1,15 @@
+"""GPU-box experiment: phase statistics of the wave tracer (debug build libyart_hip_stats.so)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from yart_amd import api, scenes
+api.LIB_COUNT_PATH = os.path.join(ROOT, "yart_amd", "libyart_hip_stats.so")
+scene, p = scenes.sponza_class(960, 540, 64, 8, tex=256, sky=256)
+ds = api.DeviceScene(scene, device=0, instrumented=True)
+img, st = ds.render(p, flags=2)
+c = ds.debug_counters()
+names = ["outer", "walk-node", "inner/pop", "tri", "slowpath", "leaf", "refill"]
+print("ms extend %.1f connect %.1f" % (st["ms_extend"], st["ms_connect"]))
+for k, n in enumerate(names):
+    it, act = c[8 + 2 * k], c[9 + 2 * k]
+    print(f"{n:10s} wave-iterations {it:12d}  active lanes {act:14d}  util {act / max(it, 1) / 64:.3f}")

@@ -1,0 +1,20 @@
+"""GPU-box experiment: stage timings of the wavefront pipeline variants on a reduced C3
+workload (same scene, 960x540, 64 spp). Usage: python tools/trace_ab.py [flags ...]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from yart_amd import api, scenes
+
+w, h, spp = 960, 540, 64
+scene, p = scenes.sponza_class(w, h, spp, 8, tex=256, sky=256)
+ds = api.DeviceScene(scene, device=0)
+flags = [int(x) for x in sys.argv[1:]] or [0, 2]
+ref = None
+for rep in range(2):
+    for f in flags:
+        img, st = ds.render(p, flags=f)
+        if ref is None:
+            ref = img
+        same = bool((img.view("u4") == ref.view("u4")).all())
+        print(f"flags={f} rep={rep} total={st['ms_device']:8.1f} ms  extend={st['ms_extend']:7.1f} connect={st['ms_connect']:7.1f} "
+              f"shade={st['ms_shade']:7.1f} gmon={st['ms_gmon']:5.1f}  Msamples/s={w*h*spp/st['ms_device']*1e-3:7.1f} identical={same}", flush=True)

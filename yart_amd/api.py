@@ -111,7 +111,7 @@ class Stats(C.Structure):
 EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error",
            "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
            "yart_hip_render", "yart_hip_render_device", "yart_hip_probe_samples",
-           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy"]
+           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_debug_counters"]
 
 LIB_COUNT_PATH = os.path.join(_HERE, "libyart_hip_count.so")   # instrumented twin (exact test counters)
 _libs = {}
@@ -269,6 +269,12 @@ class DeviceScene:
         _check(self._L.yart_hip_probe_hits(self._h, len(a), a.ctypes.data_as(C.c_void_p),
                                          out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def debug_counters(self):
+        out = (C.c_uint64 * 32)()
+        self._L.yart_hip_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+        _check(self._L.yart_hip_debug_counters(self._h, out), self._L)
+        return [int(v) for v in out]
 
     def bvh(self, mesh: int):
         nn, nt = C.c_uint32(), C.c_uint32()

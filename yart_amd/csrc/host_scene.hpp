@@ -154,6 +154,8 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
     const YartMeshDesc& m = d.meshes[mi];
     require(m.positions && m.normals && m.tangents && m.uvs && m.faces && m.n_faces > 0 && m.n_vertices > 0,
             "mesh: null array or empty mesh");
+    // traversal stack entries pack (leftFirst | span << 27): node and leaf indices < 2^27
+    require(m.n_faces < (1u << 26), "mesh: more than 2^26 triangles per mesh are not supported");
     for (uint32_t f = 0; f < m.n_faces; f++) {
       require(m.faces[4 * f] < m.n_vertices && m.faces[4 * f + 1] < m.n_vertices &&
               m.faces[4 * f + 2] < m.n_vertices, "mesh: vertex index out of range");
@@ -216,8 +218,11 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
     {   // pad[0] bit 0: this node's transform and all its ancestors' are exactly the identity
       static const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
       bool ident = std::memcmp(n.fwd, I, 64) == 0 && std::memcmp(n.inv, I, 64) == 0;
-      if (i > 0) ident = ident && (im.nodes[n.parent].pad[0] & 1u);
-      nd.pad[0] = ident ? 1u : 0u;
+      const bool parentIdent = i == 0 || (im.nodes[n.parent].pad[0] & 1u);
+      if (i > 0) ident = ident && parentIdent;
+      // bit 1: the PARENT's chain is the identity (or there is no parent): the ray in the
+      // parent's object space is the world ray (+0.0f)
+      nd.pad[0] = (ident ? 1u : 0u) | (parentIdent ? 2u : 0u);
     }
     require(nd.depth < kMaxNodeDepth, "scene graph deeper than 8 levels");
     if (nd.depth > im.maxNodeDepth) im.maxNodeDepth = nd.depth;

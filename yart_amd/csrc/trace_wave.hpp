@@ -37,7 +37,8 @@ struct TraceResult {
 };
 
 constexpr uint32_t kRefillMin = 20;     // refill when at least this many lanes are idle
-constexpr uint32_t kInnerBurst = 24;    // inner/pop steps between refill checks
+constexpr uint32_t kInnerBurst = 32;    // max inner/pop steps per scheduling round
+constexpr uint32_t kInnerMin = 12;      // leave the inner loop when fewer lanes than this still step
 
 // Fetch(k, job): load queue entry k.  Commit(job, result): store the result of a finished ray.
 template <bool NEE, class Fetch, class Commit>
@@ -60,153 +61,175 @@ __device__ __forceinline__ void traceWave(const SceneDev& sc, const SamplerConfi
   const LeafTri* leaves = sc.leafTris;
   uint32_t meshIdx = 0;
   AlphaCtx actx; actx.sampler = &job.smp; actx.cfg = scfg;
+  NodeRayCache cache;
+  cache.o = mk3(0); cache.d = mk3(0);
 
+  // Wave-uniform scheduling: every iteration the wave runs ONE phase, chosen by how many
+  // lanes are waiting for it; lanes in other states wait. Per ray the operation order is
+  // untouched (each lane walks its own state machine), only the interleaving changes.
   for (;;) {
-    // ------------------------------------------------------------------ refill
+    const bool walking = has && !inMesh;
+    const bool atLeaf = has && inMesh && span > 0 && d < hit.t;
+    const bool stepping = has && inMesh && !atLeaf;
     const unsigned long long idle = __ballot(!has);
-    if (idle != 0 && !exhausted && (uint32_t(__popcll(idle)) >= kRefillMin || idle == ~0ull)) {
-      const uint32_t n = uint32_t(__popcll(idle));
+    const uint32_t nIdle = uint32_t(__popcll(idle));
+    const uint32_t nWalk = uint32_t(__popcll(__ballot(walking)));
+    const uint32_t nLeaf = uint32_t(__popcll(__ballot(atLeaf)));
+    const uint32_t nStep = uint32_t(__popcll(__ballot(stepping)));
+    if (nIdle == 64u && exhausted) break;
+
+    // ------------------------------------------------------------------ refill
+    if (!exhausted && (nIdle >= kRefillMin || nIdle == 64u)) {
       const int leader = __ffsll((long long) idle) - 1;
       uint32_t base = 0;
-      if (int(lane) == leader) base = atomicAdd(cursor, n);
+      if (int(lane) == leader) base = atomicAdd(cursor, nIdle);
       base = __shfl(base, leader);
-      if (base + n >= count) exhausted = true;                 // wave-uniform
+      if (base + nIdle >= count) exhausted = true;             // wave-uniform
       if (!has) {
         const uint32_t k = base + uint32_t(__popcll(idle & laneLt));
         if (k < count) {
+          WF_PHASE(tally, 6);                                   // refills / rays fetched
           fetch(k, job);
-          has = true; inMesh = false; nodeI = 0; didHit = false;
+          has = true; inMesh = false; nodeI = 0; didHit = false; cache.node = -2;
           hit.t = job.tMax; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
           attenuation = mk3(1.0f);
           YART_COUNT(nTrav, 1);
         }
       }
+      continue;
     }
-    if (__ballot(has) == 0) {
-      if (exhausted) break;
-      continue;                                                // every lane idle: refill at the top
-    }
+    if (has) WF_PHASE(tally, 0);                               // scheduling rounds / lanes holding a ray
 
-    // ------------------------------------------------------------------ scene-graph walk
-    if (has && !inMesh) {
-      while (nodeI < sc.nNodes) {
-        const NodeDev& nd = sc.nodes[nodeI];
-        f3 oo, od;
-        if (nd.pad[0] & 1u) { oo = job.o + 0.0f; od = job.d + 0.0f; }      // identity chain
-        else objectRay(sc, nodeI, job.o, job.d, oo, od);
-        ray = makeRay(oo, od);
-        float dd;
-        YART_COUNT(nBox, 1);
-        if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) { nodeI = nd.skip; continue; }
-        if (nd.mesh >= 0) {
-          const MeshDev& mesh = sc.meshes[nd.mesh];
-          meshIdx = uint32_t(nd.mesh);
-          nodes = sc.bvhNodes + mesh.nodeOffset;
-          leaves = sc.leafTris + mesh.leafOffset;
-          const BvhNode root = nodes[0];
-          YART_COUNT(nBox, 1);
-          if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {          // testBVH entry (:95)
-            inMesh = true; leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
-            break;
+    if (nStep > 0 && nStep >= nWalk && nStep >= nLeaf) {
+      // ---------------------------------------------------------------- inner / pop steps
+      for (uint32_t burst = 0; burst < kInnerBurst; burst++) {
+        const bool go = has && inMesh && !(span > 0 && d < hit.t);
+        const uint32_t nGo = uint32_t(__popcll(__ballot(go)));
+        if (nGo == 0 || (burst > 0 && nGo < kInnerMin)) break;
+        if (go) {
+          WF_PHASE(tally, 2);
+          bool pop = true;
+          if (d < hit.t) {                                      // inner node: test both children
+            const BvhNode c1 = nodes[leftFirst], c2 = nodes[leftFirst + 1];
+            YART_COUNT(nBox, 2);
+            float d1, d2;
+            const bool hit1 = testBox(ray, tMin, hit.t, c1.bmin, c1.bmax, d1);
+            const bool hit2 = testBox(ray, tMin, hit.t, c2.bmin, c2.bmax, d2);
+            if (hit1 || hit2) {
+              const bool firstNear = hit1 && !(hit2 && d1 > d2);
+              if (hit1 && hit2)
+                stackPush(stk, stackIdx++, firstNear ? (c2.leftFirst | (c2.span << kSpanShift))
+                                                     : (c1.leftFirst | (c1.span << kSpanShift)),
+                          firstNear ? d2 : d1);
+              d = firstNear ? d1 : d2;
+              leftFirst = firstNear ? c1.leftFirst : c2.leftFirst;
+              span = firstNear ? c1.span : c2.span;
+              pop = false;
+            }
+          }
+          if (pop) {
+            if (stackIdx == 0) {                                // testBVH returns: back to the walk
+              inMesh = false; didHit |= meshDidHit; nodeI++;
+            } else {
+              uint32_t link;
+              stackPop(stk, --stackIdx, link, d);
+              leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
+            }
           }
         }
-        nodeI++;
       }
-      if (!inMesh) {                                            // walk finished: ray done
-        TraceResult r;
-        r.t = hit.t; r.u = hit.u; r.v = hit.v; r.tri = hit.tri; r.node = hit.node; r.backSide = hit.backSide;
-        r.hit = didHit; r.attenuation = attenuation; r.dim = job.smp.dim;
-        commit(job, r);
-        has = false;
-      }
-    }
-
-    // ------------------------------------------------------------------ inner / pop steps
-    uint32_t burst = 0;
-    while (has && inMesh && !(span > 0 && d < hit.t)) {
-      bool pop = true;
-      if (d < hit.t) {                                          // inner node: test both children
-        const BvhNode c1 = nodes[leftFirst], c2 = nodes[leftFirst + 1];
-        YART_COUNT(nBox, 2);
-        float d1, d2;
-        const bool hit1 = testBox(ray, tMin, hit.t, c1.bmin, c1.bmax, d1);
-        const bool hit2 = testBox(ray, tMin, hit.t, c2.bmin, c2.bmax, d2);
-        if (hit1 || hit2) {
-          const bool firstNear = hit1 && !(hit2 && d1 > d2);    // child1 is taken unless swapped / missed
-          if (hit1 && hit2) {
-            const uint32_t farNode = firstNear ? leftFirst + 1 : leftFirst;
-            stackPush(stk, stackIdx++, farNode, firstNear ? d2 : d1);
-          }
-          d = firstNear ? d1 : d2;
-          const uint32_t lf = firstNear ? c1.leftFirst : c2.leftFirst;
-          span = firstNear ? c1.span : c2.span;
-          leftFirst = lf;
-          pop = false;
+    } else if (nLeaf > 0 && nLeaf >= nWalk) {
+      // ---------------------------------------------------------------- leaf: triangles in index order
+      if (atLeaf) {
+        WF_PHASE(tally, 5);
+        const MeshDev& mesh = sc.meshes[meshIdx];
+        for (uint32_t i = 0; i < span; i++) {
+          WF_PHASE(tally, 3);
+          const LeafTri tr = leaves[leftFirst + i];
+          YART_COUNT(nTri, 1);
+          const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
+          const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
+          const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
+          bool accepted = false;
+          do {
+            const f3 rayEdge2 = cross(ray.d, edge2);
+            const float det = dot(edge1, rayEdge2);
+            if (double(fabsf(det)) < 1e-12) break;
+            const float invDet = 1.0f / det;
+            const f3 b = ray.o - p0;
+            const float u = dot(b, rayEdge2) * invDet;
+            if (u < 0.0f || u > 1.0f) break;
+            const f3 bEdge1 = cross(b, edge1);
+            const float v = dot(ray.d, bEdge1) * invDet;
+            if (v < 0.0f || u + v > 1.0f) break;
+            const float t = dot(edge2, bEdge1) * invDet;
+            if (t <= tMin || hit.t <= t) break;
+            if (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) {
+              WF_PHASE(tally, 4);                               // alpha / transparent slow path
+              f2 uv; f3 n;
+              interpUVN(sc, mesh, tr.triIdx, u, v, uv, n);
+              const MaterialDev& mt = sc.materials[tr.material];
+              if (tr.matFlags & MAT_HAS_ALPHA) {
+                float alpha = matAlpha(sc, mt, uv);
+                if (alpha < 1.0f && get1D(job.smp, scfg) > alpha) break;
+              }
+              if (NEE && (tr.matFlags & MAT_TRANSPARENT)) {
+                attenuation *= absDot(n, ray.d) * matBase(sc, mt, uv);
+                break;
+              }
+            }
+            hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeI;
+            hit.backSide = det < 0 ? 1u : 0u;
+            accepted = true;
+          } while (false);
+          meshDidHit |= accepted;
+          if (NEE && meshDidHit) break;
         }
-      }
-      if (pop) {
-        if (stackIdx == 0) {                                    // testBVH returns: back to the walk
+        if (stackIdx == 0) {
           inMesh = false; didHit |= meshDidHit; nodeI++;
         } else {
-          uint32_t nodeId;
-          stackPop(stk, --stackIdx, nodeId, d);
-          const BvhNode nn = nodes[nodeId];
-          leftFirst = nn.leftFirst; span = nn.span;
+          uint32_t link;
+          stackPop(stk, --stackIdx, link, d);
+          leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
         }
       }
-      if (++burst >= kInnerBurst) break;
-    }
-
-    // ------------------------------------------------------------------ leaf
-    if (has && inMesh && span > 0 && d < hit.t) {
-      const MeshDev& mesh = sc.meshes[meshIdx];
-      for (uint32_t i = 0; i < span; i++) {
-        const LeafTri tr = leaves[leftFirst + i];
-        YART_COUNT(nTri, 1);
-        const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
-        const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
-        const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
-        bool accepted = false;
-        do {
-          const f3 rayEdge2 = cross(ray.d, edge2);
-          const float det = dot(edge1, rayEdge2);
-          if (double(fabsf(det)) < 1e-12) break;
-          const float invDet = 1.0f / det;
-          const f3 b = ray.o - p0;
-          const float u = dot(b, rayEdge2) * invDet;
-          if (u < 0.0f || u > 1.0f) break;
-          const f3 bEdge1 = cross(b, edge1);
-          const float v = dot(ray.d, bEdge1) * invDet;
-          if (v < 0.0f || u + v > 1.0f) break;
-          const float t = dot(edge2, bEdge1) * invDet;
-          if (t <= tMin || hit.t <= t) break;
-          if (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) {
-            f2 uv; f3 n;
-            interpUVN(sc, mesh, tr.triIdx, u, v, uv, n);
-            const MaterialDev& mt = sc.materials[tr.material];
-            if (tr.matFlags & MAT_HAS_ALPHA) {
-              float alpha = matAlpha(sc, mt, uv);
-              if (alpha < 1.0f && get1D(job.smp, scfg) > alpha) break;
+    } else {
+      // ---------------------------------------------------------------- scene-graph walk: one node
+      if (walking) {
+        WF_PHASE(tally, 1);
+        if (nodeI < sc.nNodes) {
+          const NodeDev& nd = sc.nodes[nodeI];
+          f3 oo, od;
+          nodeObjectRay(sc, nodeI, nd, job.o, job.d, cache, oo, od);
+          ray = makeRay(oo, od);
+          float dd;
+          YART_COUNT(nBox, 1);
+          if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) {
+            nodeI = nd.skip;
+          } else {
+            bool entered = false;
+            if (nd.mesh >= 0) {
+              const MeshDev& mesh = sc.meshes[nd.mesh];
+              meshIdx = uint32_t(nd.mesh);
+              nodes = sc.bvhNodes + mesh.nodeOffset;
+              leaves = sc.leafTris + mesh.leafOffset;
+              const BvhNode root = nodes[0];
+              YART_COUNT(nBox, 1);
+              if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {      // testBVH entry (:95)
+                inMesh = true; leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
+                entered = true;
+              }
             }
-            if (NEE && (tr.matFlags & MAT_TRANSPARENT)) {
-              attenuation *= absDot(n, ray.d) * matBase(sc, mt, uv);
-              break;
-            }
+            if (!entered) nodeI++;
           }
-          hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeI;
-          hit.backSide = det < 0 ? 1u : 0u;
-          accepted = true;
-        } while (false);
-        meshDidHit |= accepted;
-        if (NEE && meshDidHit) break;
-      }
-      if (stackIdx == 0) {
-        inMesh = false; didHit |= meshDidHit; nodeI++;
-      } else {
-        uint32_t nodeId;
-        stackPop(stk, --stackIdx, nodeId, d);
-        const BvhNode nn = nodes[nodeId];
-        leftFirst = nn.leftFirst; span = nn.span;
+        }
+        if (!inMesh && nodeI >= sc.nNodes) {                    // walk finished: ray done
+          TraceResult r;
+          r.t = hit.t; r.u = hit.u; r.v = hit.v; r.tri = hit.tri; r.node = hit.node; r.backSide = hit.backSide;
+          r.hit = didHit; r.attenuation = attenuation; r.dim = job.smp.dim;
+          commit(job, r);
+          has = false;
+        }
       }
     }
   }

@@ -46,17 +46,29 @@ YART_HD bool testBox(const RayO& r, float tIntMin, float tIntMax, const float* b
   float lo_z = r.sz ? bmax[2] : bmin[2], hi_z = r.sz ? bmin[2] : bmax[2];
   float tmin0 = lo_x * r.idir.x + r.odir.x, tmin1 = lo_y * r.idir.y + r.odir.y, tmin2 = lo_z * r.idir.z + r.odir.z;
   float tmax0 = hi_x * r.idir.x + r.odir.x, tmax1 = hi_y * r.idir.y + r.odir.y, tmax2 = hi_z * r.idir.z + r.odir.z;
+  // Reference: t0 = max(tmin[i], t0) with max(m,n) = m > n ? m : n, t1 = min(tmax[i], t1)
+  // likewise. t0 / t1 themselves are never NaN (they start from tMin / hit.t and a NaN
+  // candidate loses the comparison), so IEEE maxNum / minNum — which also return the
+  // non-NaN operand — give the same value; they compile to v_max3_f32 / v_min3_f32.
   float t0 = tIntMin, t1 = tIntMax;
-  t0 = ymax(tmin0, t0); t0 = ymax(tmin1, t0); t0 = ymax(tmin2, t0);
-  t1 = ymin(tmax0, t1); t1 = ymin(tmax1, t1); t1 = ymin(tmax2, t1);
+  t0 = fmaxf(tmin0, t0); t0 = fmaxf(tmin1, t0); t0 = fmaxf(tmin2, t0);
+  t1 = fminf(tmax0, t1); t1 = fminf(tmax1, t1); t1 = fminf(tmax2, t1);
   d = t0;
   return t1 >= t0;
 }
 
 // Lane-private traversal stack: entry k of this lane is lds[k * ldsStride] for
 // k < ldsDepth, spill[(k - ldsDepth) * spillStride] beyond.
+// The LDS part is addressed through an LDS-address-space pointer so that it compiles to
+// ds_write_b64 / ds_read_b64 (a generic pointer selected against the spill pointer turns
+// every pop into a flat_load with a full vmcnt+lgkmcnt wait).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+#else
+typedef uint64_t lds_u64;
+#endif
 struct TravStack {
-  uint64_t* lds; uint32_t ldsStride; uint32_t ldsDepth;
+  lds_u64* lds; uint32_t ldsStride; uint32_t ldsDepth;
   uint64_t* spill; uint32_t spillStride;
 };
 YART_HD void stackPush(const TravStack& s, uint32_t k, uint32_t node, float d) {
@@ -66,7 +78,9 @@ YART_HD void stackPush(const TravStack& s, uint32_t k, uint32_t node, float d) {
   else s.spill[(k - s.ldsDepth) * s.spillStride] = e;
 }
 YART_HD void stackPop(const TravStack& s, uint32_t k, uint32_t& node, float& d) {
-  uint64_t e = (k < s.ldsDepth) ? s.lds[k * s.ldsStride] : s.spill[(k - s.ldsDepth) * s.spillStride];
+  uint64_t e;
+  if (k < s.ldsDepth) e = s.lds[k * s.ldsStride];
+  else e = s.spill[(k - s.ldsDepth) * s.spillStride];
   node = uint32_t(e);
   d = __builtin_bit_cast(float, uint32_t(e >> 32));
 }
@@ -110,100 +124,108 @@ YART_HD void interpUVN(const SceneDev& sc, const MeshDev& mesh, uint32_t tri, fl
 }
 
 // testBVH (ray-integrator.cpp:84-160) + testTriangle (:163-229) for one mesh.
+//
+// Same per-ray operation order as the reference's loop, arranged for SIMT execution:
+//  * "while-while": inner-node and pop steps run in a tight loop until the lane stands
+//    at a leaf it has to test (d < hit.t) or has left the tree; the leaf's triangle loop
+//    then runs — lanes of a wave reconverge on the (rare, expensive) leaf code instead of
+//    interleaving it with other lanes' inner steps;
+//  * a stack entry carries the far child's link word (leftFirst | span << 27) and entry
+//    distance, so a pop needs no dependent node fetch before the children can be loaded.
+constexpr uint32_t kSpanShift = 27;            // leftFirst < 2^27 (checked at scene build)
 template <bool NEE>
 YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t nodeIdx, const RayO& ray,
                           float tMin, HitRec& hit, f3& attenuation, const TravStack& stk,
                           AlphaCtx& actx) {
   const BvhNode* nodes = sc.bvhNodes + mesh.nodeOffset;
   const LeafTri* leaves = sc.leafTris + mesh.leafOffset;
-  uint32_t node = 0;
   uint32_t stackIdx = 0;
   bool didHit = false;
   float d;
-  {
-    const BvhNode root = nodes[0];
-    YART_COUNT(nBox, 1);
-    if (!testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) return false;
-  }
-  uint32_t leftFirst = nodes[0].leftFirst, span = nodes[0].span;
-  while (true) {
-    if (d < hit.t) {
-      if (span > 0) {
-        for (uint32_t i = 0; i < span; i++) {
-          const LeafTri tr = leaves[leftFirst + i];
-          YART_COUNT(nTri, 1);
-          const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
-          const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
-          const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
-          bool accepted = false;
-          do {
-            const f3 rayEdge2 = cross(ray.d, edge2);
-            const float det = dot(edge1, rayEdge2);
-            if (double(fabsf(det)) < 1e-12) break;          // math_base.hpp:11 epsilon is a double
-            const float invDet = 1.0f / det;
-            const f3 b = ray.o - p0;
-            const float u = dot(b, rayEdge2) * invDet;
-            if (u < 0.0f || u > 1.0f) break;
-            const f3 bEdge1 = cross(b, edge1);
-            const float v = dot(ray.d, bEdge1) * invDet;
-            if (v < 0.0f || u + v > 1.0f) break;
-            const float t = dot(edge2, bEdge1) * invDet;
-            if (t <= tMin || hit.t <= t) break;
-            if (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) {
-              // slow path: alpha cut-outs and NEE-transparent surfaces
-              f2 uv; f3 n;
-              interpUVN(sc, mesh, tr.triIdx, u, v, uv, n);
-              const MaterialDev& mt = sc.materials[tr.material];
-              if (tr.matFlags & MAT_HAS_ALPHA) {
-                float alpha = matAlpha(sc, mt, uv);
-                if (alpha < 1.0f && get1D(*actx.sampler, actx.cfg) > alpha) break;
-              }
-              if (NEE && (tr.matFlags & MAT_TRANSPARENT)) {
-                attenuation *= absDot(n, ray.d) * matBase(sc, mt, uv);
-                break;
-              }
-            }
-            hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeIdx;
-            hit.backSide = det < 0 ? 1u : 0u;
-            accepted = true;
-          } while (false);
-          didHit |= accepted;
-          if (NEE && didHit) break;
-        }
-        if (stackIdx == 0) break;
-        stackPop(stk, --stackIdx, node, d);
-      } else {
+  const BvhNode root = nodes[0];
+  YART_COUNT(nBox, 1);
+  if (!testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) return false;
+  uint32_t leftFirst = root.leftFirst, span = root.span;
+  bool alive = true;
+  while (alive) {
+    // ---- inner nodes and pops, until a leaf must be tested
+    while (alive && !(span > 0 && d < hit.t)) {
+      bool pop = true;
+      if (d < hit.t) {
         const BvhNode c1 = nodes[leftFirst], c2 = nodes[leftFirst + 1];
         YART_COUNT(nBox, 2);
         float d1, d2;
-        bool hit1 = testBox(ray, tMin, hit.t, c1.bmin, c1.bmax, d1);
-        bool hit2 = testBox(ray, tMin, hit.t, c2.bmin, c2.bmax, d2);
-        uint32_t n1 = leftFirst, n2 = leftFirst + 1;
-        if (hit1) {
-          if (hit2) {
-            if (d1 > d2) { float td = d1; d1 = d2; d2 = td; uint32_t tn = n1; n1 = n2; n2 = tn; }
-            stackPush(stk, stackIdx++, n2, d2);
-          }
-          node = n1; d = d1;
-          // children are already in registers: take their link fields directly
-          const bool first = (n1 == leftFirst);
-          leftFirst = first ? c1.leftFirst : c2.leftFirst;
-          span = first ? c1.span : c2.span;
-          continue;
-        } else if (hit2) {
-          node = n2; d = d2;
-          leftFirst = c2.leftFirst; span = c2.span;
-          continue;
-        } else {
-          if (stackIdx == 0) break;
-          stackPop(stk, --stackIdx, node, d);
+        const bool hit1 = testBox(ray, tMin, hit.t, c1.bmin, c1.bmax, d1);
+        const bool hit2 = testBox(ray, tMin, hit.t, c2.bmin, c2.bmax, d2);
+        if (hit1 || hit2) {
+          // child1 is the near one unless it was missed or (both hit and d1 > d2)
+          const bool firstNear = hit1 && !(hit2 && d1 > d2);
+          if (hit1 && hit2)
+            stackPush(stk, stackIdx++, firstNear ? (c2.leftFirst | (c2.span << kSpanShift))
+                                                 : (c1.leftFirst | (c1.span << kSpanShift)),
+                      firstNear ? d2 : d1);
+          d = firstNear ? d1 : d2;
+          leftFirst = firstNear ? c1.leftFirst : c2.leftFirst;
+          span = firstNear ? c1.span : c2.span;
+          pop = false;
         }
       }
-    } else {
-      if (stackIdx == 0) break;
-      stackPop(stk, --stackIdx, node, d);
+      if (pop) {
+        if (stackIdx == 0) alive = false;
+        else {
+          uint32_t link;
+          stackPop(stk, --stackIdx, link, d);
+          leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
+        }
+      }
     }
-    leftFirst = nodes[node].leftFirst; span = nodes[node].span;
+    if (!alive) break;
+    // ---- leaf: triangles in index order
+    for (uint32_t i = 0; i < span; i++) {
+      const LeafTri tr = leaves[leftFirst + i];
+      YART_COUNT(nTri, 1);
+      const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
+      const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
+      const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
+      bool accepted = false;
+      do {
+        const f3 rayEdge2 = cross(ray.d, edge2);
+        const float det = dot(edge1, rayEdge2);
+        if (double(fabsf(det)) < 1e-12) break;          // math_base.hpp:11 epsilon is a double
+        const float invDet = 1.0f / det;
+        const f3 b = ray.o - p0;
+        const float u = dot(b, rayEdge2) * invDet;
+        if (u < 0.0f || u > 1.0f) break;
+        const f3 bEdge1 = cross(b, edge1);
+        const float v = dot(ray.d, bEdge1) * invDet;
+        if (v < 0.0f || u + v > 1.0f) break;
+        const float t = dot(edge2, bEdge1) * invDet;
+        if (t <= tMin || hit.t <= t) break;
+        if (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) {
+          // slow path: alpha cut-outs and NEE-transparent surfaces
+          f2 uv; f3 n;
+          interpUVN(sc, mesh, tr.triIdx, u, v, uv, n);
+          const MaterialDev& mt = sc.materials[tr.material];
+          if (tr.matFlags & MAT_HAS_ALPHA) {
+            float alpha = matAlpha(sc, mt, uv);
+            if (alpha < 1.0f && get1D(*actx.sampler, actx.cfg) > alpha) break;
+          }
+          if (NEE && (tr.matFlags & MAT_TRANSPARENT)) {
+            attenuation *= absDot(n, ray.d) * matBase(sc, mt, uv);
+            break;
+          }
+        }
+        hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeIdx;
+        hit.backSide = det < 0 ? 1u : 0u;
+        accepted = true;
+      } while (false);
+      didHit |= accepted;
+      if (NEE && didHit) break;
+    }
+    if (stackIdx == 0) break;
+    uint32_t link;
+    stackPop(stk, --stackIdx, link, d);
+    leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
   }
   return didHit;
 }
@@ -211,6 +233,13 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
 // World ray -> object space of scene node `idx`: the reference re-derives the ray at
 // every level from its parent's object-space ray (ray-integrator.cpp:26-29).
 YART_HD void objectRay(const SceneDev& sc, uint32_t idx, f3 o, f3 d, f3& oo, f3& od) {
+  if (sc.nodes[idx].pad[0] & 1u) {
+    // every transform on the chain is the identity: each 4x4 product reduces to x + 0.0f
+    // (accumulation from +0 turns -0 into +0, everything else is unchanged), and that is
+    // idempotent, so one application equals the reference's depth+1 applications
+    oo = o + 0.0f; od = d + 0.0f;
+    return;
+  }
   uint32_t chain[kMaxNodeDepth];
   uint32_t n = 0;
   for (int32_t i = int32_t(idx); i >= 0 && n < kMaxNodeDepth; i = sc.nodes[i].parent) chain[n++] = uint32_t(i);
@@ -222,6 +251,29 @@ YART_HD void objectRay(const SceneDev& sc, uint32_t idx, f3 o, f3 d, f3& oo, f3&
   oo = o; od = d;
 }
 
+// Object-space ray of consecutive scene nodes without re-walking the ancestor chain: the
+// reference hands each child the parent's object-space ray (ray-integrator.cpp:26-29), so
+// siblings share it. One cached (parent node, ray) pair covers a pre-order walk of groups
+// of siblings; identity chains need no cache (world ray + 0.0f).
+struct NodeRayCache {
+  int32_t node = -2;
+  f3 o, d;
+};
+YART_HD void nodeObjectRay(const SceneDev& sc, uint32_t idx, const NodeDev& nd, f3 wo, f3 wd,
+                           NodeRayCache& cache, f3& oo, f3& od) {
+  if (nd.pad[0] & 1u) { oo = wo + 0.0f; od = wd + 0.0f; return; }
+  f3 po, pd;
+  if (nd.pad[0] & 2u) { po = wo + 0.0f; pd = wd + 0.0f; }
+  else if (nd.parent == cache.node) { po = cache.o; pd = cache.d; }
+  else {
+    objectRay(sc, uint32_t(nd.parent), wo, wd, po, pd);
+    cache.node = nd.parent; cache.o = po; cache.d = pd;
+  }
+  (void)idx;
+  oo = mulPoint(nd.xf.inv, po);
+  od = mulVector(nd.xf.inv, pd);
+}
+
 // testNode (ray-integrator.cpp:20-54) as a pre-order walk. hit.t carries tMax in.
 template <bool NEE>
 YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& hit, f3& attenuation,
@@ -229,10 +281,11 @@ YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& h
   bool didHit = false;
   uint32_t i = 0;
   YART_COUNT(nTrav, 1);
+  NodeRayCache cache;
   while (i < sc.nNodes) {
     const NodeDev& nd = sc.nodes[i];
     f3 oo, od;
-    objectRay(sc, i, o, d, oo, od);
+    nodeObjectRay(sc, i, nd, o, d, cache, oo, od);
     RayO ray = makeRay(oo, od);
     float dd;
     YART_COUNT(nBox, 1);
@@ -278,6 +331,13 @@ YART_HD Hit finalizeHit(const SceneDev& sc, const HitRec& r, f3 o, f3 d) {
   f3 p = h.p;
   for (int32_t i = int32_t(r.node); i >= 0; i = sc.nodes[i].parent) {
     const NodeDev& a = sc.nodes[i];
+    if (a.pad[0] & 1u) {
+      // identity from here to the root: p, tg map to x + 0.0f; the normal is still
+      // renormalised once per level (transform.hpp:71), which is not idempotent
+      p = p + 0.0f; tang = tang + 0.0f;
+      for (uint32_t k = 0; k <= a.depth; k++) n = normalized(n + 0.0f);
+      break;
+    }
     p = mulPoint(a.xf.fwd, p);
     n = mulNormalT(a.xf.inv, n);       // m_normalTransform = transpose(float3x3(inverse))
     tang = mulVector(a.xf.fwd, tang);

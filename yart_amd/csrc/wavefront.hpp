@@ -36,7 +36,24 @@ struct WfTally {
 #if defined(YART_COUNT_TRAVERSAL)
   uint32_t box = 0, tri = 0, trav = 0, shade = 0;
 #endif
+#if defined(YART_TRACE_STATS)
+  // debug build: wave-iteration / active-lane counts per phase of the wave tracer
+  // (pairs: [2k] wave iterations, [2k+1] lanes active in them)
+  uint32_t ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 };
+#if defined(YART_TRACE_STATS)
+// to be executed by every active lane of a divergent region: the lowest active lane counts
+// the wave iteration, every active lane counts itself
+#define WF_PHASE(t, k)                                                                  \
+  do {                                                                                  \
+    const unsigned long long _m = __ballot(true);                                       \
+    (t).ph[2 * (k)] += (int(threadIdx.x & 63u) == __ffsll((long long) _m) - 1) ? 1u : 0u; \
+    (t).ph[2 * (k) + 1] += 1u;                                                          \
+  } while (0)
+#else
+#define WF_PHASE(t, k) ((void)0)
+#endif
 #if defined(YART_COUNT_TRAVERSAL)
 #define WF_TALLY_TRAV(t, ac) ((t).box += (ac).nBox, (t).tri += (ac).nTri, (t).trav += (ac).nTrav)
 #define WF_TALLY_SHADE(t) ((t).shade++)

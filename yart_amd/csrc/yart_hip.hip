@@ -40,6 +40,7 @@ constexpr int kBlock = 256;            // 4 waves per workgroup
 constexpr int kLdsStack = 24;          // traversal stack entries kept in LDS per lane (8 B each)
 constexpr int kSpillDepth = int(kRefStackDepth) - kLdsStack;
 constexpr int kSpillDepthMax = int(kRefStackDepth);   // spill area sized for the shallowest LDS stack
+constexpr int kNumCounters = 32;       // [0] rays, [1..4] instrumented tallies, [8..31] debug statistics
 
 thread_local std::string g_lastError;
 
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(MegaArgs a) {
   PathCtx cx;
   cx.sc = &a.sc;
   cx.sobol = reinterpret_cast<const uint32_t*>(a.sc.lut + LutDev::sobol);
-  cx.stk.lds = ldsStack + threadIdx.x; cx.stk.ldsStride = kBlock; cx.stk.ldsDepth = kLdsStack;
+  cx.stk.lds = (lds_u64*)(ldsStack + threadIdx.x); cx.stk.ldsStride = kBlock; cx.stk.ldsDepth = kLdsStack;
   cx.stk.spill = a.spill + gtid; cx.stk.spillStride = nthreads;
   cx.rc = a.rc;
   const uint32_t total = a.nPixels * a.spp;
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(kBlock) k_probe_samples(ProbeSampleArgs a) {
   PathCtx cx;
   cx.sc = &a.sc;
   cx.sobol = reinterpret_cast<const uint32_t*>(a.sc.lut + LutDev::sobol);
-  cx.stk.lds = ldsStack + threadIdx.x; cx.stk.ldsStride = kBlock; cx.stk.ldsDepth = kLdsStack;
+  cx.stk.lds = (lds_u64*)(ldsStack + threadIdx.x); cx.stk.ldsStride = kBlock; cx.stk.ldsDepth = kLdsStack;
   cx.stk.spill = a.spill + gtid; cx.stk.spillStride = gridDim.x * blockDim.x;
   cx.rc = a.rc;
   if (gtid >= a.n) return;
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(kBlock) k_probe_hits(ProbeHitArgs a) {
   __shared__ uint64_t ldsStack[kLdsStack * kBlock];
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
   TravStack stk;
-  stk.lds = ldsStack + threadIdx.x; stk.ldsStride = kBlock; stk.ldsDepth = kLdsStack;
+  stk.lds = (lds_u64*)(ldsStack + threadIdx.x); stk.ldsStride = kBlock; stk.ldsDepth = kLdsStack;
   stk.spill = a.spill + gtid; stk.spillStride = gridDim.x * blockDim.x;
   if (gtid >= a.n) return;
   const float* r = a.rays + size_t(gtid) * 6;
@@ -247,6 +248,7 @@ struct YartScene {
   DevBuf<f4> wf[9];                        // wavefront path state (wavefront.hpp::WfState)
   DevBuf<uint32_t> qA, qB, qS, wfCounters; // wavefront queues
   std::vector<uint32_t> pixelsHost;
+  unsigned long long lastCounters[32] = {0};
   uint32_t pixW = 0, pixH = 0, pixTile = 0, pixRank = 0, pixWorld = 0;
   std::mutex mu;
 };
@@ -385,8 +387,8 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const uint32_t nPix = uint32_t(s.pixelsHost.size());
 
   HIP_CHECK(hipMemsetAsync(dOut, 0, size_t(W) * H * 4 * sizeof(float), stream));
-  s.cursor.ensure(1); s.counters.ensure(8);
-  HIP_CHECK(hipMemsetAsync(s.counters.p, 0, 8 * sizeof(unsigned long long), stream));
+  s.cursor.ensure(1); s.counters.ensure(kNumCounters);
+  HIP_CHECK(hipMemsetAsync(s.counters.p, 0, kNumCounters * sizeof(unsigned long long), stream));
 
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
   const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend), 5);
@@ -394,7 +396,10 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shade), 8);
   const int gridTrE = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_extend), 8);
   const int gridTrS = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_shadow), 8);
+  // closest-hit rays: one-ray-per-lane kernel unless YART_FLAG_WAVE_TRACE; shadow rays: wave tracer
+  // (dynamic refill pays off on their heavy-tailed lengths) unless YART_FLAG_SIMPLE_SHADOW
   const bool simpleTrace = (p.flags & YART_FLAG_WAVE_TRACE) == 0;
+  const bool simpleShadow = (p.flags & YART_FLAG_SIMPLE_SHADOW) != 0;
   s.spill.ensure(size_t(std::max(std::max(gridMega, gridTrE), std::max(std::max(gridExtend, gridConnect), gridTrS))) *
                  kBlock * kSpillDepthMax);
 
@@ -463,11 +468,11 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           HIP_CHECK(hipGetLastError());
           tShade.end(stream);
           tConnect.begin(stream);
-          if (simpleTrace) hipLaunchKernelGGL(k_wf_connect, dim3(gridConnect), dim3(kBlock), 0, stream, a);
+          if (simpleShadow) hipLaunchKernelGGL(k_wf_connect, dim3(gridConnect), dim3(kBlock), 0, stream, a);
           else hipLaunchKernelGGL(k_wf_trace_shadow, dim3(gridTrS), dim3(kTrBlock), 0, stream, a);
           HIP_CHECK(hipGetLastError());
           tConnect.end(stream);
-          if (!simpleTrace) {
+          if (!simpleShadow) {
             tShade.begin(stream);
             hipLaunchKernelGGL(k_wf_post, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
             HIP_CHECK(hipGetLastError());
@@ -496,8 +501,9 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   HIP_CHECK(hipEventRecord(tAll.b, stream));
   HIP_CHECK(hipEventSynchronize(tAll.b));
   float msAll = 0; HIP_CHECK(hipEventElapsedTime(&msAll, tAll.a, tAll.b));
-  unsigned long long cnt[8] = {0};
+  unsigned long long cnt[kNumCounters] = {0};
   HIP_CHECK(hipMemcpy(cnt, s.counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+  for (int i = 0; i < kNumCounters; i++) s.lastCounters[i] = cnt[i];
   if (stats) {
     *stats = YartStats{};
     stats->samples = uint64_t(nPix) * p.samples;
@@ -639,6 +645,13 @@ int yart_hip_probe_hits(YartScene* scene, uint32_t n, const float* rays, float* 
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(out, res.p, size_t(n) * 16 * 4, hipMemcpyDeviceToHost));
+  });
+}
+
+int yart_hip_debug_counters(YartScene* scene, uint64_t* out32) {
+  return guarded([&] {
+    require(scene && out32, "null pointer");
+    for (int i = 0; i < kNumCounters; i++) out32[i] = scene->lastCounters[i];
   });
 }
 

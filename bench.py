@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--flags", type=int, default=0, help="YART_FLAG_* pipeline variant (A/B experiments)")
     return ap.parse_args()
 
 
@@ -100,7 +101,7 @@ def main():
     last = {}
 
     def step():
-        st = dscene.render_into(fb, p, rank=rank, world_size=world, stream=stream)
+        st = dscene.render_into(fb, p, rank=rank, world_size=world, flags=args.flags, stream=stream)
         last.update(st)
         if world > 1:
             # non-owned tiles are exactly 0 on every rank -> the sum is the merged frame
@@ -140,7 +141,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "sponza_class (generated atrium, %d triangles, env-lit) %dx%d, %d spp, %d bounces"
                                % (scene.n_triangles, W, H, p["spp"], p["depth"]),
-                   "pipeline": "wavefront", "tiles": "64x64 Morton round-robin over ranks",
+                   "pipeline": "megakernel" if args.flags & 1 else "wavefront", "tiles": "64x64 Morton round-robin over ranks",
                    "parallelism": f"tiles/{world}"},
         "rays_per_step": int(last.get("rays", 0)),
     }

@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from yart_amd import api, scenes
 
+if os.environ.get("YART_LIB"):          # experiment variant built by tools/build_variant.sh
+    api.LIB_PATH = os.path.join(ROOT, "yart_amd", "_variants", os.environ["YART_LIB"] + ".so")
+    print("variant", os.environ["YART_LIB"], flush=True)
 w, h, spp = 960, 540, 64
 scene, p = scenes.sponza_class(w, h, spp, 8, tex=256, sky=256)
 ds = api.DeviceScene(scene, device=0)

@@ -48,13 +48,14 @@ __device__ __forceinline__ void traceWave(const SceneDev& sc, const SamplerConfi
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long laneLt = (1ull << lane) - 1ull;
   const float tMin = 0.001f;
-  bool has = false, exhausted = false, inMesh = false;
+  const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+  bool has = false, exhausted = false, inMesh = false, firstFill = true;
   TraceJob job;
   job.o = mk3(0); job.d = mk3(0); job.tMax = 0; job.slot = 0; job.smp.dim = 0; job.smp.morton = 0;
   RayO ray = makeRay(mk3(0), mk3(1));
   HitRec hit; hit.t = 0; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
   f3 attenuation = mk3(1.0f);
-  bool didHit = false, meshDidHit = false;
+  bool didHit = false, meshDidHit = false, rayIsWorld = false;
   uint32_t nodeI = 0, leftFirst = 0, span = 0, stackIdx = 0;
   float d = 0.0f;
   const BvhNode* nodes = sc.bvhNodes;
@@ -81,16 +82,23 @@ __device__ __forceinline__ void traceWave(const SceneDev& sc, const SamplerConfi
     // ------------------------------------------------------------------ refill
     if (!exhausted && (nIdle >= kRefillMin || nIdle == 64u)) {
       const int leader = __ffsll((long long) idle) - 1;
-      uint32_t base = 0;
-      if (int(lane) == leader) base = atomicAdd(cursor, nIdle);
-      base = __shfl(base, leader);
-      if (base + nIdle >= count) exhausted = true;             // wave-uniform
+      uint32_t base;
+      if (firstFill) {                                          // by wave index, no atomic
+        firstFill = false;
+        base = waveId * 64u;
+        if (nWaves * 64u >= count) exhausted = true;
+      } else {
+        base = 0;
+        if (int(lane) == leader) base = atomicAdd(cursor, nIdle);
+        base = nWaves * 64u + __shfl(base, leader);
+        if (base + nIdle >= count) exhausted = true;           // wave-uniform
+      }
       if (!has) {
         const uint32_t k = base + uint32_t(__popcll(idle & laneLt));
         if (k < count) {
           WF_PHASE(tally, 6);                                   // refills / rays fetched
           fetch(k, job);
-          has = true; inMesh = false; nodeI = 0; didHit = false; cache.node = -2;
+          has = true; inMesh = false; nodeI = 0; didHit = false; cache.node = -2; rayIsWorld = false;
           hit.t = job.tMax; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
           attenuation = mk3(1.0f);
           YART_COUNT(nTrav, 1);
@@ -110,11 +118,12 @@ __device__ __forceinline__ void traceWave(const SceneDev& sc, const SamplerConfi
           WF_PHASE(tally, 2);
           bool pop = true;
           if (d < hit.t) {                                      // inner node: test both children
-            const BvhNode c1 = nodes[leftFirst], c2 = nodes[leftFirst + 1];
+            const BvhNode* pair = nodes + leftFirst;
+            const BvhNode c1 = pair[0], c2 = pair[1];
             YART_COUNT(nBox, 2);
             float d1, d2;
-            const bool hit1 = testBox(ray, tMin, hit.t, c1.bmin, c1.bmax, d1);
-            const bool hit2 = testBox(ray, tMin, hit.t, c2.bmin, c2.bmax, d2);
+            bool hit1, hit2;
+            testBox2(ray, tMin, hit.t, c1, c2, hit1, hit2, d1, d2);
             if (hit1 || hit2) {
               const bool firstNear = hit1 && !(hit2 && d1 > d2);
               if (hit1 && hit2)
@@ -199,9 +208,14 @@ __device__ __forceinline__ void traceWave(const SceneDev& sc, const SamplerConfi
         WF_PHASE(tally, 1);
         if (nodeI < sc.nNodes) {
           const NodeDev& nd = sc.nodes[nodeI];
-          f3 oo, od;
-          nodeObjectRay(sc, nodeI, nd, job.o, job.d, cache, oo, od);
-          ray = makeRay(oo, od);
+          if (nd.pad[0] & 1u) {                                 // identity chain: the world ray (+0), made once
+            if (!rayIsWorld) { ray = makeRay(job.o + 0.0f, job.d + 0.0f); rayIsWorld = true; }
+          } else {
+            f3 oo, od;
+            nodeObjectRay(sc, nodeI, nd, job.o, job.d, cache, oo, od);
+            ray = makeRay(oo, od);
+            rayIsWorld = false;
+          }
           float dd;
           YART_COUNT(nBox, 1);
           if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) {

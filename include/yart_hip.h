@@ -116,10 +116,10 @@ typedef struct YartRenderParams {
   uint32_t reserved[4];
 } YartRenderParams;
 
-#define YART_FLAG_MEGAKERNEL 1u   /* single-kernel integrator instead of the wavefront pipeline */
-#define YART_FLAG_SIMPLE_SHADOW 4u /* shadow rays with the one-ray-per-lane kernel (A/B) */
-#define YART_FLAG_WAVE_TRACE 2u   /* closest-hit rays with the wave-level tracer too (trace_wave.hpp:
-                                     dynamic refill + while-while); A/B alternative to the default kernels */
+#define YART_FLAG_MEGAKERNEL 1u     /* single-kernel integrator instead of the wavefront pipeline */
+#define YART_FLAG_WAVE_TRACE 2u     /* wave-level tracer kernels (trace_wave.hpp: dynamic refill + while-while)
+                                       for both ray kinds; A/B alternative to the default kernels */
+#define YART_FLAG_GENERAL_TRACE 4u  /* general traversal kernels for every ray instead of lean kernels + retry */
 
 /* Renderer::RenderData counters (src/core/renderer.hpp:22-28) + per-stage device time. */
 typedef struct YartStats {

@@ -42,6 +42,7 @@ struct HostImage {
   float totalPower = 0.0f;
   uint32_t maxNodeDepth = 0;
   uint32_t nLights = 0, nInfinite = 0, nArea = 0, nMaterials = 0;   // real counts (the vectors are padded)
+  bool allIdentity = true;   // every node's transform chain is exactly the identity (TRAV_IDENTITY kernels)
 
   SceneDev view() const {
     SceneDev s{};
@@ -223,6 +224,7 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
       // bit 1: the PARENT's chain is the identity (or there is no parent): the ray in the
       // parent's object space is the world ray (+0.0f)
       nd.pad[0] = (ident ? 1u : 0u) | (parentIdent ? 2u : 0u);
+      if (!ident) im.allIdentity = false;
     }
     require(nd.depth < kMaxNodeDepth, "scene graph deeper than 8 levels");
     if (nd.depth > im.maxNodeDepth) im.maxNodeDepth = nd.depth;

@@ -131,9 +131,20 @@ struct HitRec {              // what the walk tracks of cpu/hit.hpp
 #define YART_COUNT(field, n) ((void)0)
 #endif
 
+// Traversal variants (template parameter MODE of traverseMesh / traverseScene):
+//   TRAV_FAST      no alpha / transparency code: a candidate hit on such a triangle sets
+//                  AlphaCtx::deferred and abandons the ray, which the caller then traces again
+//                  with the general variant (results are per ray, so a restart is exact). The
+//                  side path (texture fetches + a ZSobol draw) costs ~20 VGPRs in the leaf loop.
+//   TRAV_IDENTITY  every scene node's transform chain is the identity (checked at scene build):
+//                  no 4x4 products, the world ray (+0) is used for every node; ~30 VGPRs.
+// Together they bring the closest-hit kernel from 127 to 74 VGPRs, i.e. from 4 to 6 waves/SIMD.
+enum : int { TRAV_GENERAL = 0, TRAV_FAST = 1, TRAV_IDENTITY = 2 };
+
 struct AlphaCtx {            // state the stochastic alpha test draws from
   Sampler* sampler;
   SamplerConfig cfg;
+  bool deferred = false;     // TRAV_FAST: the ray met an alpha / transparent candidate
 #if defined(YART_COUNT_TRAVERSAL)
   uint32_t nBox = 0, nTri = 0, nTrav = 0;
 #endif
@@ -162,7 +173,7 @@ YART_HD void interpUVN(const SceneDev& sc, const MeshDev& mesh, uint32_t tri, fl
 //  * a stack entry carries the far child's link word (leftFirst | span << 27) and entry
 //    distance, so a pop needs no dependent node fetch before the children can be loaded.
 constexpr uint32_t kSpanShift = 27;            // leftFirst < 2^27 (checked at scene build)
-template <bool NEE>
+template <bool NEE, int MODE = TRAV_GENERAL>
 YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t nodeIdx, const RayO& ray,
                           float tMin, HitRec& hit, f3& attenuation, const TravStack& stk,
                           AlphaCtx& actx) {
@@ -231,7 +242,11 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
         if (v < 0.0f || u + v > 1.0f) break;
         const float t = dot(edge2, bEdge1) * invDet;
         if (t <= tMin || hit.t <= t) break;
-        if (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) {
+        if ((MODE & TRAV_FAST) && (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT))) {
+          actx.deferred = true;
+          return false;
+        }
+        if (!(MODE & TRAV_FAST) && (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT))) {
           // slow path: alpha cut-outs and NEE-transparent surfaces
           f2 uv; f3 n;
           interpUVN(sc, mesh, tr.triIdx, u, v, uv, n);
@@ -305,7 +320,7 @@ YART_HD void nodeObjectRay(const SceneDev& sc, uint32_t idx, const NodeDev& nd, 
 }
 
 // testNode (ray-integrator.cpp:20-54) as a pre-order walk. hit.t carries tMax in.
-template <bool NEE>
+template <bool NEE, int MODE = TRAV_GENERAL>
 YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& hit, f3& attenuation,
                            const TravStack& stk, AlphaCtx& actx) {
   bool didHit = false;
@@ -316,9 +331,9 @@ YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& h
   bool rayIsWorld = false;       // `ray` holds makeRay(o + 0, d + 0): shared by every identity-chain node
   while (i < sc.nNodes) {
     const NodeDev& nd = sc.nodes[i];
-    if (nd.pad[0] & 1u) {
+    if ((MODE & TRAV_IDENTITY) || (nd.pad[0] & 1u)) {
       if (!rayIsWorld) { ray = makeRay(o + 0.0f, d + 0.0f); rayIsWorld = true; }
-    } else {
+    } else if (!(MODE & TRAV_IDENTITY)) {
       f3 oo, od;
       nodeObjectRay(sc, i, nd, o, d, cache, oo, od);
       ray = makeRay(oo, od);
@@ -327,8 +342,10 @@ YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& h
     float dd;
     YART_COUNT(nBox, 1);
     if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) { i = nd.skip; continue; }
-    if (nd.mesh >= 0)
-      didHit |= traverseMesh<NEE>(sc, sc.meshes[nd.mesh], i, ray, tMin, hit, attenuation, stk, actx);
+    if (nd.mesh >= 0) {
+      didHit |= traverseMesh<NEE, MODE>(sc, sc.meshes[nd.mesh], i, ray, tMin, hit, attenuation, stk, actx);
+      if ((MODE & TRAV_FAST) && actx.deferred) return false;
+    }
     i++;
   }
   return didHit;

@@ -118,6 +118,7 @@ YART_HD void wfGenerate(const RenderConst& rc, const uint32_t* sobol, const Came
 }
 
 // extend: closest hit; only the sampler dimension can change (alpha tests)
+// extend, general variant: every triangle kind, any node transforms
 YART_HD void wfExtend(const SceneDev& sc, const RenderConst& rc, const TravStack& stk, const WfState& s,
                       uint32_t i, WfTally& tally) {
   const f4 r0 = s.ray0[i], r1 = s.ray1[i];
@@ -137,6 +138,52 @@ YART_HD void wfExtend(const SceneDev& sc, const RenderConst& rc, const TravStack
   h1.x = asF(hr.node | (hr.backSide << 31));
   s.hit1[i] = h1;
   if (smp.dim != dim0) { t1.w = asF(smp.dim); s.thr1[i] = t1; }
+}
+
+// extend, fast variant (traverse.hpp TRAV_FAST [| TRAV_IDENTITY]): no sampler state, no alpha
+// code. Returns false when the ray met an alpha / transparent candidate: nothing has been
+// written then and the caller queues the path for wfExtend.
+template <int MODE>
+YART_HD bool wfExtendFast(const SceneDev& sc, const TravStack& stk, const WfState& s, uint32_t i, WfTally& tally) {
+  const f4 r0 = s.ray0[i], r1 = s.ray1[i];
+  HitRec hr;
+  hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
+  f3 dummy = mk3(1.0f);
+  AlphaCtx ac; ac.sampler = nullptr; ac.cfg = SamplerConfig{};
+  const bool hit = traverseScene<false, MODE>(sc, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), 0.001f, hr, dummy, stk, ac);
+  WF_TALLY_TRAV(tally, ac);
+  if (ac.deferred) return false;
+  s.hit0[i] = mk4(hit ? hr.t : -1.0f, hr.u, hr.v, asF(hr.tri));
+  s.hit1[i].x = asF(hr.node | (hr.backSide << 31));
+  return true;
+}
+
+// shadow ray of the path in slot i (mis-integrator.cpp:137-146) -> hit0 = {attenuation, occluded};
+// the NEE contribution and the roulette are k_wf_post's. Fast variant: same contract as wfExtendFast.
+template <int MODE>
+YART_HD bool wfShadow(const SceneDev& sc, const RenderConst& rc, const TravStack& stk, const WfState& s,
+                      uint32_t i, WfTally& tally) {
+  const f4 r0 = s.ray0[i], s0 = s.sh0[i];
+  const f3 from = mk3(r0.x, r0.y, r0.z), to = mk3(s0.x, s0.y, s0.z);
+  const f3 dir = normalized(to - from);                     // :140
+  HitRec hr;
+  hr.t = length(to - from) - 0.001f;                        // :144
+  hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
+  f3 attOcc = mk3(1.0f);
+  Sampler smp; smp.dim = 0; smp.morton = 0;
+  uint32_t dim0 = 0;
+  AlphaCtx ac; ac.sampler = &smp; ac.cfg = rc.sampler;
+  if (!(MODE & TRAV_FAST)) {
+    const f4 h1 = s.hit1[i];
+    smp.dim = dim0 = asU(s.thr1[i].w);
+    smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32);
+  }
+  const bool occluded = traverseScene<true, MODE>(sc, from, dir, 0.001f, hr, attOcc, stk, ac);
+  WF_TALLY_TRAV(tally, ac);
+  if ((MODE & TRAV_FAST) && ac.deferred) return false;
+  s.hit0[i] = mk4(attOcc.x, attOcc.y, attOcc.z, occluded ? 1.0f : 0.0f);
+  if (!(MODE & TRAV_FAST) && smp.dim != dim0) s.thr1[i].w = asF(smp.dim);
+  return true;
 }
 
 enum WfShadeResult { WF_TERMINATED = 0, WF_CONTINUE = 1, WF_SHADOW = 2 };
@@ -223,29 +270,6 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
   if (p.accRoughness > 0.5f) fl |= WF_REGULARIZED;
   p.flags = fl;
   return shadow ? WF_SHADOW : WF_CONTINUE;
-}
-
-// connect: shadow traversal + NEE contribution (mis-integrator.cpp:125-133, 135-148)
-YART_HD void wfConnect(const SceneDev& sc, const RenderConst& rc, const TravStack& stk, const WfState& s,
-                       uint32_t i, WfPath& p, uint32_t& rays, WfTally& tally) {
-  p = wfLoad(s, i);
-  const f4 s0 = s.sh0[i], s1 = s.sh1[i], s2 = s.sh2[i];
-  const f3 from = p.o, to = mk3(s0.x, s0.y, s0.z);
-  f3 dir = normalized(to - from);
-  HitRec hr;
-  hr.t = length(to - from) - 0.001f;
-  hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
-  f3 attOcc = mk3(1.0f);
-  AlphaCtx ac; ac.sampler = &p.smp; ac.cfg = rc.sampler;
-  bool occluded = traverseScene<true>(sc, from, dir, 0.001f, hr, attOcc, stk, ac);
-  WF_TALLY_TRAV(tally, ac);
-  const f3 attPre = mk3(s1.x, s1.y, s1.z), Lif = mk3(s2.x, s2.y, s2.z);
-  if (!occluded) {
-    rays++;
-    p.L += attPre * (Lif * attOcc * s0.w / s1.w);
-  } else {
-    p.L += attPre * mk3(0.0f);          // Ld returned {}: L += attenuation * 0 (NaN/inf propagation)
-  }
 }
 
 }  // namespace yart_hip

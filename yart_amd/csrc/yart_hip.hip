@@ -246,7 +246,7 @@ struct YartScene {
   DevBuf<uint32_t> pixels; DevBuf<float> L; DevBuf<uint32_t> cursor; DevBuf<unsigned long long> counters;
   DevBuf<uint64_t> spill; DevBuf<float> hdr; DevBuf<uint32_t> probeIn; DevBuf<float> probeOut;
   DevBuf<f4> wf[9];                        // wavefront path state (wavefront.hpp::WfState)
-  DevBuf<uint32_t> qA, qB, qS, wfCounters; // wavefront queues
+  DevBuf<uint32_t> qA, qB, qS, qR, wfCounters; // wavefront queues
   std::vector<uint32_t> pixelsHost;
   unsigned long long lastCounters[32] = {0};
   uint32_t pixW = 0, pixH = 0, pixTile = 0, pixRank = 0, pixWorld = 0;
@@ -390,18 +390,24 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   s.cursor.ensure(1); s.counters.ensure(kNumCounters);
   HIP_CHECK(hipMemsetAsync(s.counters.p, 0, kNumCounters * sizeof(unsigned long long), stream));
 
+  // lean traversal kernels when the scene allows them (every node transform chain the identity ->
+  // identity-only variant); YART_FLAG_GENERAL_TRACE forces the general kernels for everything
+  const bool general = (p.flags & YART_FLAG_GENERAL_TRACE) != 0;
+  const bool waveTrace = (p.flags & YART_FLAG_WAVE_TRACE) != 0;
+  const bool ident = s.host.allIdentity;
+  auto kExtendFast = ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
+  auto kShadowFast = ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>;
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
-  const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend), 5);
-  const int gridConnect = persistentGrid(s, reinterpret_cast<const void*>(k_wf_connect), 5);
+  const int gridExtendFast = persistentGrid(s, reinterpret_cast<const void*>(kExtendFast), 8);
+  const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);
+  const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend<false>), 8);
+  const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow<false>), 8);
   const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shade), 8);
   const int gridTrE = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_extend), 8);
   const int gridTrS = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_shadow), 8);
-  // closest-hit rays: one-ray-per-lane kernel unless YART_FLAG_WAVE_TRACE; shadow rays: wave tracer
-  // (dynamic refill pays off on their heavy-tailed lengths) unless YART_FLAG_SIMPLE_SHADOW
-  const bool simpleTrace = (p.flags & YART_FLAG_WAVE_TRACE) == 0;
-  const bool simpleShadow = (p.flags & YART_FLAG_SIMPLE_SHADOW) != 0;
-  s.spill.ensure(size_t(std::max(std::max(gridMega, gridTrE), std::max(std::max(gridExtend, gridConnect), gridTrS))) *
-                 kBlock * kSpillDepthMax);
+  int gridMax = std::max(std::max(gridMega, gridTrE), std::max(gridTrS, std::max(gridExtend, gridShadow)));
+  gridMax = std::max(gridMax, std::max(gridExtendFast, gridShadowFast));
+  s.spill.ensure(size_t(gridMax) * kBlock * kSpillDepthMax);
 
   // chunk the pixel list: per-sample radiance buffer <= ~1.5 GiB, wavefront state <= kWfMaxPaths
   const uint32_t maxWave = std::min(p.max_wave_samples, p.samples);
@@ -415,7 +421,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   if (!mega) {
     const size_t np = size_t(chunk) * waveCap;
     for (auto& b : s.wf) b.ensure(np);
-    s.qA.ensure(np); s.qB.ensure(np); s.qS.ensure(np); s.wfCounters.ensure(8);
+    s.qA.ensure(np); s.qB.ensure(np); s.qS.ensure(np); s.qR.ensure(np); s.wfCounters.ensure(WC_COUNT);
   }
 
   Timer tAll;
@@ -448,10 +454,10 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         a.sc = s.dev; a.cam = cam; a.rc = rc;
         a.st.ray0 = s.wf[0].p; a.st.ray1 = s.wf[1].p; a.st.thr0 = s.wf[2].p; a.st.thr1 = s.wf[3].p;
         a.st.hit0 = s.wf[4].p; a.st.hit1 = s.wf[5].p; a.st.sh0 = s.wf[6].p; a.st.sh1 = s.wf[7].p; a.st.sh2 = s.wf[8].p;
-        a.qA = s.qA.p; a.qB = s.qB.p; a.qS = s.qS.p; a.counters = s.wfCounters.p;
+        a.qA = s.qA.p; a.qB = s.qB.p; a.qS = s.qS.p; a.qR = s.qR.p; a.counters = s.wfCounters.p;
         a.pixels = s.pixels.p + c0; a.nPaths = n * uint32_t(waveSamples); a.spp = uint32_t(waveSamples);
         a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p; a.stats = s.counters.p; a.spill = s.spill.p;
-        const uint32_t init[8] = {a.nPaths, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t init[WC_COUNT] = {a.nPaths, 0, 0, 0, 0, 0, 0, 0};
         HIP_CHECK(hipMemcpyAsync(s.wfCounters.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
         tShade.begin(stream);
         hipLaunchKernelGGL(k_wf_generate, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
@@ -459,8 +465,15 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         tShade.end(stream);
         for (uint32_t bounce = 0; bounce < rc.maxDepth; bounce++) {
           tExtend.begin(stream);
-          if (simpleTrace) hipLaunchKernelGGL(k_wf_extend, dim3(gridExtend), dim3(kBlock), 0, stream, a);
-          else hipLaunchKernelGGL(k_wf_trace_extend, dim3(gridTrE), dim3(kTrBlock), 0, stream, a);
+          if (waveTrace) {
+            hipLaunchKernelGGL(k_wf_trace_extend, dim3(gridTrE), dim3(kTrBlock), 0, stream, a);
+          } else if (general) {
+            hipLaunchKernelGGL(k_wf_extend<false>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+          } else {
+            hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(k_wf_reset_retry, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
+          }
           HIP_CHECK(hipGetLastError());
           tExtend.end(stream);
           tShade.begin(stream);
@@ -468,16 +481,20 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           HIP_CHECK(hipGetLastError());
           tShade.end(stream);
           tConnect.begin(stream);
-          if (simpleShadow) hipLaunchKernelGGL(k_wf_connect, dim3(gridConnect), dim3(kBlock), 0, stream, a);
-          else hipLaunchKernelGGL(k_wf_trace_shadow, dim3(gridTrS), dim3(kTrBlock), 0, stream, a);
+          if (waveTrace) {
+            hipLaunchKernelGGL(k_wf_trace_shadow, dim3(gridTrS), dim3(kTrBlock), 0, stream, a);
+          } else if (general) {
+            hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
+          } else {
+            hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
+          }
           HIP_CHECK(hipGetLastError());
           tConnect.end(stream);
-          if (!simpleShadow) {
-            tShade.begin(stream);
-            hipLaunchKernelGGL(k_wf_post, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
-            HIP_CHECK(hipGetLastError());
-            tShade.end(stream);
-          }
+          tShade.begin(stream);
+          hipLaunchKernelGGL(k_wf_post, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
+          HIP_CHECK(hipGetLastError());
+          tShade.end(stream);
           hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
           HIP_CHECK(hipGetLastError());
           std::swap(a.qA, a.qB);

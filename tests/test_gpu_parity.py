@@ -32,7 +32,8 @@ def api(built):
     return api
 
 
-PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+wave_trace": 2, "wavefront+general_trace": 4}
+PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+wave_trace": 2, "wavefront+general_trace": 4,
+                  "wavefront+direct_sampler": 8}
 
 
 @pytest.mark.parametrize("pipeline", list(PIPELINE_FLAGS))

@@ -32,6 +32,7 @@ YART_OK, YART_E_INVALID, YART_E_NO_DEVICE, YART_E_HIP, YART_E_IO = 0, -1, -2, -3
 FLAG_MEGAKERNEL = 1
 FLAG_WAVE_TRACE = 2
 FLAG_GENERAL_TRACE = 4
+FLAG_DIRECT_SAMPLER = 8
 
 
 class YartError(RuntimeError):

@@ -518,10 +518,15 @@ YART_HD BsdfSample sampleClearcoat(const MaterialDev& mt, f3 wo, const GGX& mf, 
 }
 
 // ---- lobe mixture in the local frame (parametric.cpp:84-258) ----
-YART_HD f3 bsdfFImpl(const SceneDev& sc, const MaterialDev& mt, f3 _wo, f3 _wi, f2 uv) {
+// The *E variants take the material parameters already fetched (matEvaluate): the wavefront shade
+// stage evaluates sample / f / pdf at the same hit and fetches the textures once.
+YART_HD MatEval matEvaluate(const SceneDev& sc, const MaterialDev& mt, f2 uv) {
   MatEval e;
   e.base = matBase(sc, mt, uv);
   matFetchScalars(sc, mt, uv, e);
+  return e;
+}
+YART_HD f3 bsdfFImplE(const SceneDev& sc, const MaterialDev& mt, const MatEval& e, f3 _wo, f3 _wi) {
   GGX mf = makeGGX(e.r, mt.anisotropic);
   const float cMetallic = e.m;
   const float cDielectric = (1.0f - e.m) * e.t;
@@ -539,9 +544,10 @@ YART_HD f3 bsdfFImpl(const SceneDev& sc, const MaterialDev& mt, f3 _wo, f3 _wi, 
   }
   return val;
 }
-YART_HD float bsdfPdfImpl(const SceneDev& sc, const MaterialDev& mt, f3 wo, f3 wi, f2 uv) {
-  MatEval e;
-  matFetchScalars(sc, mt, uv, e);
+YART_HD f3 bsdfFImpl(const SceneDev& sc, const MaterialDev& mt, f3 _wo, f3 _wi, f2 uv) {
+  return bsdfFImplE(sc, mt, matEvaluate(sc, mt, uv), _wo, _wi);
+}
+YART_HD float bsdfPdfImplE(const SceneDev& sc, const MaterialDev& mt, const MatEval& e, f3 wo, f3 wi) {
   GGX mf = makeGGX(e.r, mt.anisotropic);
   const float pMetallic = e.m;
   const float pDielectric = (1.0f - e.m) * e.t;
@@ -558,11 +564,14 @@ YART_HD float bsdfPdfImpl(const SceneDev& sc, const MaterialDev& mt, f3 wo, f3 w
   }
   return pdf;
 }
-YART_HD BsdfSample bsdfSampleImpl(const SceneDev& sc, const MaterialDev& mt, f3 _wo, f2 uv, f2 u,
-                                  float uc, float uc2, bool regularized) {
+YART_HD float bsdfPdfImpl(const SceneDev& sc, const MaterialDev& mt, f3 wo, f3 wi, f2 uv) {
   MatEval e;
-  e.base = matBase(sc, mt, uv);
+  e.base = mk3(0);
   matFetchScalars(sc, mt, uv, e);
+  return bsdfPdfImplE(sc, mt, e, wo, wi);
+}
+YART_HD BsdfSample bsdfSampleImplE(const SceneDev& sc, const MaterialDev& mt, MatEval e, f3 _wo, f2 uv, f2 u,
+                                   float uc, float uc2, bool regularized) {
   if (regularized) {
     e.r = roughen(e.r);
     e.cr = roughen(e.cr);
@@ -597,6 +606,10 @@ YART_HD BsdfSample bsdfSampleImpl(const SceneDev& sc, const MaterialDev& mt, f3 
     s.wi = mul3x3(mt.invRot, s.wi);
   }
   return s;
+}
+YART_HD BsdfSample bsdfSampleImpl(const SceneDev& sc, const MaterialDev& mt, f3 _wo, f2 uv, f2 u,
+                                  float uc, float uc2, bool regularized) {
+  return bsdfSampleImplE(sc, mt, matEvaluate(sc, mt, uv), _wo, uv, u, uc, uc2, regularized);
 }
 
 // ---- world-space wrappers (core/bsdf.cpp:5-58) ----

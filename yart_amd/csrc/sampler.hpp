@@ -9,9 +9,28 @@
 
 namespace yart_hip {
 
+// Per-render tables that hoist the sample-independent part of the ZSobol index permutation
+// out of the per-sample work (sampler.hpp:155-173: the permutation of a base-4 digit depends
+// on the dimension and on the HIGHER digits only, so the digits that lie in the pixel bits of
+// the Morton index — and the permutation rows of the first two sample digits — are the same
+// for all samples of a pixel). One 64-bit entry per (dimension, pixel of this rank's list):
+//   bits  0..23  permuted pixel digits, as (index >> log2spp)
+//   bits 24..31  permutation row of the top sample digit       (higher digits = pixel)
+//   bits 32..63  rows of the second sample digit, one byte per value of the (unpermuted) top one
+// plus hashDim(d) for d <= dims, and byte-wise XOR tables of the Sobol' dimension-1 matrix.
+// A draw then costs 2 table reads + the remaining (spp-dependent) low digits instead of
+// nBase4Digits 64-bit hash evaluations. Dimensions >= dims fall back to the direct evaluation.
+struct SamplerTables {
+  const uint64_t* entries = nullptr;   // [dims][stride]
+  const uint64_t* hash = nullptr;      // [dims + 3]
+  const uint32_t* sobol1 = nullptr;    // [8][256]: XOR of the matrix columns selected by byte b of the index
+  uint32_t dims = 0, stride = 0;
+};
+
 struct SamplerConfig {
   uint32_t log2spp;       // log2Int(float(spp)), math_base.hpp:156-160
   uint32_t nBase4Digits;  // log2Int(roundUpPow2(tile)) + (log2spp+1)/2, sampler.hpp:74-82
+  SamplerTables tab;      // optional (wavefront pipeline)
 };
 
 // math_base.hpp:156-160 — rounds to nearest in log space (48 -> 6)
@@ -32,6 +51,7 @@ inline SamplerConfig makeSamplerConfig(uint32_t spp, uint32_t tileSize) {
   uint32_t res = uint32_t(roundUpPow2Host(int32_t(tileSize)));
   uint32_t log4spp = (c.log2spp + 1) / 2;
   c.nBase4Digits = uint32_t(log2IntHost(float(res))) + log4spp;
+  c.tab = SamplerTables{};
   return c;
 }
 
@@ -83,6 +103,7 @@ YART_HD uint32_t sobolDim1Column(uint32_t k) {
 struct Sampler {
   uint64_t morton;
   uint32_t dim;
+  uint32_t pix = 0;          // SamplerTables column of this path's pixel
 };
 
 // permutations[24][4] of sampler.hpp:115-140, 2 bits per entry, one byte per row,
@@ -101,7 +122,12 @@ YART_HD void startPixelSample(Sampler& s, const SamplerConfig& c, uint32_t px, u
   s.morton = (encodeMorton2(px, py) << c.log2spp) | uint64_t(sample);
 }
 
-YART_HD uint64_t getSampleIndex(const Sampler& s, const SamplerConfig& c) {   // sampler.hpp:155-173
+// one digit of the permutation: row of permutations[][] for the digit whose higher digits are `higher`
+YART_HD uint32_t permutationRowFor(uint64_t higher, uint64_t dimMix) {
+  return permutationRow(uint32_t((mixBits(higher ^ dimMix) >> 24) % 24ull));
+}
+
+YART_HD uint64_t getSampleIndexDirect(const Sampler& s, const SamplerConfig& c) {   // sampler.hpp:155-173
   uint64_t index = 0;
   const bool pow2Samples = c.log2spp & 1u;
   const int lastDigit = pow2Samples ? 1 : 0;
@@ -110,12 +136,61 @@ YART_HD uint64_t getSampleIndex(const Sampler& s, const SamplerConfig& c) {   //
     uint32_t digitShift = uint32_t(2 * i - lastDigit);
     uint32_t digit = uint32_t(s.morton >> digitShift) & 3u;
     uint64_t higherDigits = s.morton >> (digitShift + 2);
-    uint32_t p = uint32_t((mixBits(higherDigits ^ dimMix) >> 24) % 24ull);
-    digit = (permutationRow(p) >> (2u * digit)) & 3u;
+    digit = (permutationRowFor(higherDigits, dimMix) >> (2u * digit)) & 3u;
     index |= uint64_t(digit) << digitShift;
   }
   if (pow2Samples) {
     uint32_t digit = uint32_t(s.morton & 1ull);
+    index |= uint64_t(digit ^ uint32_t(mixBits((s.morton >> 1) ^ dimMix) & 1ull));
+  }
+  return index;
+}
+
+// Digit bookkeeping shared by the table builder and the table reader. Digits i >= firstPixelDigit
+// lie entirely in the pixel bits (a digit never straddles: digitShift has the parity of log2spp).
+YART_HD int samplerFirstPixelDigit(const SamplerConfig& c) { return int((c.log2spp + 1u) / 2u); }
+
+YART_HD uint64_t samplerTableEntry(const SamplerConfig& c, uint64_t pixelMorton, uint32_t dim) {
+  const int lastDigit = int(c.log2spp & 1u);
+  const uint64_t dimMix = uint64_t(0x55555555u * dim);
+  const uint64_t morton = pixelMorton << c.log2spp;
+  const int firstPix = samplerFirstPixelDigit(c);
+  uint64_t index = 0;
+  for (int i = int(c.nBase4Digits) - 1; i >= firstPix; i--) {
+    const uint32_t digitShift = uint32_t(2 * i - lastDigit);
+    const uint32_t digit = uint32_t(morton >> digitShift) & 3u;
+    index |= uint64_t((permutationRowFor(morton >> (digitShift + 2), dimMix) >> (2u * digit)) & 3u) << digitShift;
+  }
+  uint64_t e = (index >> c.log2spp) & 0xffffffull;
+  e |= uint64_t(permutationRowFor(pixelMorton, dimMix)) << 24;
+  for (uint32_t k = 0; k < 4; k++) e |= uint64_t(permutationRowFor((pixelMorton << 2) | k, dimMix)) << (32 + 8 * k);
+  return e;
+}
+
+YART_HD uint64_t getSampleIndex(const Sampler& s, const SamplerConfig& c) {
+  if (c.tab.entries == nullptr || s.dim >= c.tab.dims) return getSampleIndexDirect(s, c);
+  const uint64_t e = c.tab.entries[size_t(s.dim) * c.tab.stride + s.pix];
+  const int lastDigit = int(c.log2spp & 1u);
+  const uint64_t dimMix = uint64_t(0x55555555u * s.dim);
+  uint64_t index = (e & 0xffffffull) << c.log2spp;
+  int i = samplerFirstPixelDigit(c) - 1;                        // top sample digit
+  if (i >= lastDigit) {
+    const uint32_t shift = uint32_t(2 * i - lastDigit);
+    const uint32_t top = uint32_t(s.morton >> shift) & 3u;
+    index |= uint64_t((uint32_t(e >> 24) >> (2u * top)) & 3u) << shift;
+    if (--i >= lastDigit) {
+      const uint32_t shift2 = shift - 2u;
+      const uint32_t digit = uint32_t(s.morton >> shift2) & 3u;
+      index |= uint64_t((uint32_t(e >> (32u + 8u * top)) >> (2u * digit)) & 3u) << shift2;
+      for (--i; i >= lastDigit; i--) {                          // remaining digits: direct
+        const uint32_t digitShift = uint32_t(2 * i - lastDigit);
+        const uint32_t dg = uint32_t(s.morton >> digitShift) & 3u;
+        index |= uint64_t((permutationRowFor(s.morton >> (digitShift + 2), dimMix) >> (2u * dg)) & 3u) << digitShift;
+      }
+    }
+  }
+  if (lastDigit) {
+    const uint32_t digit = uint32_t(s.morton & 1ull);
     index |= uint64_t(digit ^ uint32_t(mixBits((s.morton >> 1) ^ dimMix) & 1ull));
   }
   return index;
@@ -135,17 +210,28 @@ YART_HD float sobolDim1(uint64_t idx, uint32_t seed, const uint32_t* __restrict_
   return sobolToFloat(fastOwen(v, seed));
 }
 
+YART_HD uint64_t samplerHash(const SamplerConfig& c, uint32_t dim) {
+  return (c.tab.hash != nullptr && dim < c.tab.dims + 3u) ? c.tab.hash[dim] : hashDim(dim);
+}
+YART_HD float sobolDim1Tab(uint64_t idx, uint32_t seed, const uint32_t* __restrict__ byteTab) {
+  uint32_t v = 0;
+  for (uint32_t b = 0; idx != 0; idx >>= 8, b++) v ^= byteTab[b * 256u + uint32_t(idx & 0xffull)];
+  return sobolToFloat(fastOwen(v, seed));
+}
+
 YART_HD float get1D(Sampler& s, const SamplerConfig& c) {           // sampler.hpp:89-94
   uint64_t idx = getSampleIndex(s, c);
   s.dim++;
-  uint32_t h = uint32_t(hashDim(s.dim));
+  uint32_t h = uint32_t(samplerHash(c, s.dim));
   return sobolDim0(idx, h);
 }
 YART_HD f2 get2D(Sampler& s, const SamplerConfig& c, const uint32_t* __restrict__ matrix52) {   // :96-107
   uint64_t idx = getSampleIndex(s, c);
   s.dim += 2;
-  uint64_t hb = hashDim(s.dim);
-  return mk2(sobolDim0(idx, uint32_t(hb)), sobolDim1(idx, uint32_t(hb >> 32), matrix52));
+  uint64_t hb = samplerHash(c, s.dim);
+  const float y = c.tab.sobol1 != nullptr ? sobolDim1Tab(idx, uint32_t(hb >> 32), c.tab.sobol1)
+                                          : sobolDim1(idx, uint32_t(hb >> 32), matrix52);
+  return mk2(sobolDim0(idx, uint32_t(hb)), y);
 }
 
 }  // namespace yart_hip

@@ -21,7 +21,7 @@ namespace yart_hip {
 struct WfState {
   // ray0 = {o.xyz, d.x}  ray1 = {d.yz, lastPdf, accRoughness}
   // thr0 = {att.xyz, L.x} thr1 = {L.yz, flags(u32), dim(u32)}
-  // hit0 = {t, u, v, tri(u32)}  hit1 = {node|backSide<<31 (u32), morton.lo, morton.hi, slot(u32)}
+  // hit0 = {t, u, v, tri(u32)}  hit1 = {node|backSide<<31 (u32), morton.lo, morton.hi, sampler-table column (u32)}
   // sh0 = {to.xyz, cosTerm}  sh1 = {attPre.xyz, denom}  sh2 = {Lif.xyz, lightIsArea}
   f4 *ray0, *ray1, *thr0, *thr1, *hit0, *hit1, *sh0, *sh1, *sh2;
 };
@@ -79,7 +79,7 @@ YART_HD WfPath wfLoad(const WfState& s, uint32_t i) {
   WfPath p;
   p.o = mk3(r0.x, r0.y, r0.z); p.d = mk3(r0.w, r1.x, r1.y); p.lastPdf = r1.z; p.accRoughness = r1.w;
   p.att = mk3(t0.x, t0.y, t0.z); p.L = mk3(t0.w, t1.x, t1.y); p.flags = asU(t1.z); p.smp.dim = asU(t1.w);
-  p.smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32); p.slot = asU(h1.w);
+  p.smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32); p.smp.pix = asU(h1.w); p.slot = i;
   return p;
 }
 YART_HD void wfStoreRay(const WfState& s, uint32_t i, const WfPath& p) {
@@ -105,16 +105,17 @@ YART_HD bool wfRoulette(const RenderConst& rc, WfPath& p) {
 
 // generate: RayIntegrator::sample up to the first trace
 YART_HD void wfGenerate(const RenderConst& rc, const uint32_t* sobol, const CameraDev& cam, uint32_t px,
-                        uint32_t py, uint32_t sample, uint32_t slot, const WfState& s, uint32_t i) {
+                        uint32_t py, uint32_t sample, uint32_t pix, const WfState& s, uint32_t i) {
   WfPath p;
   startPixelSample(p.smp, rc.sampler, px, py, sample);
+  p.smp.pix = pix;
   f2 uvFilm = get2D(p.smp, rc.sampler, sobol);
   f2 uvLens = get2D(p.smp, rc.sampler, sobol);
   cameraRay(cam, px, py, uvFilm, uvLens, p.o, p.d);
-  p.att = mk3(1.0f); p.L = mk3(0.0f); p.lastPdf = 0.0f; p.accRoughness = 0.0f; p.flags = 0; p.slot = slot;
+  p.att = mk3(1.0f); p.L = mk3(0.0f); p.lastPdf = 0.0f; p.accRoughness = 0.0f; p.flags = 0; p.slot = i;
   wfStoreRay(s, i, p);
   wfStoreThr(s, i, p);
-  s.hit1[i] = mk4(0.0f, asF(uint32_t(p.smp.morton)), asF(uint32_t(p.smp.morton >> 32)), asF(slot));
+  s.hit1[i] = mk4(0.0f, asF(uint32_t(p.smp.morton)), asF(uint32_t(p.smp.morton >> 32)), asF(pix));
 }
 
 // extend: closest hit; only the sampler dimension can change (alpha tests)
@@ -126,7 +127,7 @@ YART_HD void wfExtend(const SceneDev& sc, const RenderConst& rc, const TravStack
   f4 h1 = s.hit1[i];
   Sampler smp;
   smp.dim = asU(t1.w);
-  smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32);
+  smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32); smp.pix = asU(h1.w);
   const uint32_t dim0 = smp.dim;
   HitRec hr;
   hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
@@ -176,7 +177,7 @@ YART_HD bool wfShadow(const SceneDev& sc, const RenderConst& rc, const TravStack
   if (!(MODE & TRAV_FAST)) {
     const f4 h1 = s.hit1[i];
     smp.dim = dim0 = asU(s.thr1[i].w);
-    smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32);
+    smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32); smp.pix = asU(h1.w);
   }
   const bool occluded = traverseScene<true, MODE>(sc, from, dir, 0.001f, hr, attOcc, stk, ac);
   WF_TALLY_TRAV(tally, ac);
@@ -220,7 +221,13 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
   float uc = get1D(p.smp, rc.sampler);
   float uc2 = get1D(p.smp, rc.sampler);
   const f3 wo = -p.d;
-  BsdfSample res = bsdfSample(sc, mt, wo, hit.n, hit.tg, hit.uv, u, uc, uc2, regularized);
+  // one shading frame and one material fetch for sample / f / pdf (core/bsdf.cpp:5-58 builds the
+  // same frame and fetches the same texels in each of the three calls)
+  const Frame fr = shadingFrame(hit.n, hit.tg);
+  const f3 woLocal = wtl(fr, wo);
+  const MatEval me = matEvaluate(sc, mt, hit.uv);
+  BsdfSample res = bsdfSampleImplE(sc, mt, me, woLocal, hit.uv, u, uc, uc2, regularized);
+  res.wi = ltw(fr, res.wi);
   if (res.scatter & SC_EMITTED) {
     if (depth == 0 || specularBounce) p.L += p.att * res.Le;
     else if (hit.lightIdx != -1) {
@@ -242,10 +249,11 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
       uint32_t li = lightSamplerSample(sc, ucl, pl);
       const LightDev& l = sc.lights[li];
       LightSample ls = lightSample(sc, l, hit.p, ul);
-      f3 f = bsdfF(sc, mt, wo, ls.wi, hit.n, hit.tg, hit.uv);
+      const f3 wiLocal = wtl(fr, ls.wi);
+      f3 f = bsdfFImplE(sc, mt, me, woLocal, wiLocal);
       if (length2(f) != 0.0f) {
         // evaluated eagerly (pure); the reference evaluates them after the occlusion test
-        float pdfBSDF = bsdfPdf(sc, mt, wo, ls.wi, hit.n, hit.tg, hit.uv);
+        float pdfBSDF = bsdfPdfImplE(sc, mt, me, woLocal, wiLocal);
         float pdfLight = pl * ls.pdf / absDot(ls.n, ls.wi);
         if (l.type == LIGHT_AREA) pdfLight *= length2(hit.p - ls.p);
         const f3 Lif = ls.Li * f;

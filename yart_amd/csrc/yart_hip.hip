@@ -247,6 +247,7 @@ struct YartScene {
   DevBuf<uint64_t> spill; DevBuf<float> hdr; DevBuf<uint32_t> probeIn; DevBuf<float> probeOut;
   DevBuf<f4> wf[9];                        // wavefront path state (wavefront.hpp::WfState)
   DevBuf<uint32_t> qA, qB, qS, qR, wfCounters; // wavefront queues
+  DevBuf<uint64_t> smpEntries, smpHash; DevBuf<uint32_t> smpSobol1;   // SamplerTables of the current render
   std::vector<uint32_t> pixelsHost;
   unsigned long long lastCounters[32] = {0};
   uint32_t pixW = 0, pixH = 0, pixTile = 0, pixRank = 0, pixWorld = 0;
@@ -429,6 +430,24 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   uint32_t waves = 0;
   HIP_CHECK(hipEventRecord(tAll.a, stream));
 
+  // sampler tables (sampler.hpp::SamplerTables) for the wavefront pipeline; they require every
+  // sample index to fit the sampler's log2spp bits (log2Int rounds to nearest, e.g. 90 spp -> 6)
+  RenderConst rcw = rc;
+  if (!mega && !(p.flags & YART_FLAG_DIRECT_SAMPLER) && nPix > 0 && uint64_t(p.samples) <= (1ull << rc.sampler.log2spp)) {
+    const uint32_t dims = std::min<uint32_t>(256u, (4u + 8u * p.max_depth + 16u + 7u) & ~7u);
+    s.smpEntries.ensure(size_t(dims) * nPix); s.smpHash.ensure(dims + 3); s.smpSobol1.ensure(8 * 256);
+    SamplerTabArgs ta{};
+    ta.cfg = rc.sampler; ta.pixels = s.pixels.p; ta.nPixels = nPix; ta.dims = dims;
+    ta.entries = s.smpEntries.p; ta.hash = s.smpHash.p; ta.sobol1 = s.smpSobol1.p;
+    ta.matrix52 = reinterpret_cast<const uint32_t*>(s.dev.lut + LutDev::sobol);
+    tShade.begin(stream);
+    hipLaunchKernelGGL(k_sampler_tables, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, ta);
+    HIP_CHECK(hipGetLastError());
+    tShade.end(stream);
+    rcw.sampler.tab.entries = s.smpEntries.p; rcw.sampler.tab.hash = s.smpHash.p; rcw.sampler.tab.sobol1 = s.smpSobol1.p;
+    rcw.sampler.tab.dims = dims; rcw.sampler.tab.stride = nPix;
+  }
+
   // wave schedule of tile-renderer.hpp:121-124, 284-289
   uint64_t remaining = p.samples;
   uint64_t waveSamples = std::min<uint64_t>(p.first_wave_samples, p.samples);
@@ -451,7 +470,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         tMega.end(stream);
       } else {
         WfArgs a{};
-        a.sc = s.dev; a.cam = cam; a.rc = rc;
+        a.sc = s.dev; a.cam = cam; a.rc = rcw; a.pixBase = c0;
         a.st.ray0 = s.wf[0].p; a.st.ray1 = s.wf[1].p; a.st.thr0 = s.wf[2].p; a.st.thr1 = s.wf[3].p;
         a.st.hit0 = s.wf[4].p; a.st.hit1 = s.wf[5].p; a.st.sh0 = s.wf[6].p; a.st.sh1 = s.wf[7].p; a.st.sh2 = s.wf[8].p;
         a.qA = s.qA.p; a.qB = s.qB.p; a.qS = s.qS.p; a.qR = s.qR.p; a.counters = s.wfCounters.p;

@@ -117,9 +117,13 @@ def main():
     fence()
     t0 = time.perf_counter()
     kernel_ms, launches = 0.0, 0
+    lean = (args.flags & 7) == 0       # default pipeline: the dominant kernel is k_wf_extend_fast
     for _ in range(args.steps):
         step()
-        kernel_ms += last["ms_traverse"]; launches += last["launches_traverse"]
+        if lean:
+            kernel_ms += last["ms_extend_lean"]; launches += last["launches_extend_lean"]
+        else:
+            kernel_ms += last["ms_traverse"]; launches += last["launches_traverse"]
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -151,25 +155,33 @@ def main():
         # exact test counters from the instrumented twin library (one untimed pass; the
         # workload is deterministic so the counts are those of every timed pass)
         ds2 = api.DeviceScene(scene, device=local_rank, instrumented=True)
-        _, st2 = ds2.render(p)
+        _, st2 = ds2.render(p, flags=args.flags)
         ds2.close()
         shaded = st2.get("shaded_hits", 0)
-        # B_traversal = 32*N_box + 52*N_tri + 48 per traversal (closest-hit and
-        # shadow traversals = k_wf_extend + k_wf_connect launches)
-        trav_bytes = 32 * st2["box_tests"] + 52 * st2["tri_tests"] + 48 * st2["traversals"]
-        shade_bytes = 0
-        n_launch = max(1, last["launches_traverse"])
+        # B_traversal = 32*N_box + 52*N_tri + 48 per traversal. Default pipeline: the
+        # dominant kernel is the lean closest-hit kernel k_wf_extend_fast (its own counters, its own
+        # HIP-event time, one launch per bounce per batch); otherwise all traversal launches together.
+        if lean:
+            kname = "k_wf_extend_fast"
+            trav_bytes = 32 * st2["lean_box_tests"] + 52 * st2["lean_tri_tests"] + 48 * st2["lean_traversals"]
+            n_launch = max(1, last["launches_extend_lean"])
+        else:
+            kname = "k_render_mega" if args.flags & 1 else "closest-hit + shadow traversal kernels"
+            trav_bytes = 32 * st2["box_tests"] + 52 * st2["tri_tests"] + 48 * st2["traversals"]
+            n_launch = max(1, last["launches_traverse"])
         avg_ms = kernel_ms / max(1, launches)
-        achieved = (trav_bytes + shade_bytes) / n_launch / (avg_ms * 1e-3) * 1e-9
+        achieved = trav_bytes / n_launch / (avg_ms * 1e-3) * 1e-9
         out["stage_ms_per_step"] = {k: round(last[k], 2) for k in
-                                    ("ms_extend", "ms_connect", "ms_shade", "ms_gmon", "ms_device")}
+                                    ("ms_extend", "ms_extend_lean", "ms_connect", "ms_shade", "ms_gmon", "ms_device")}
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_wf_extend+k_wf_connect", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+            "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
             "avg_launch_ms": round(avg_ms, 3), "launches_per_step": n_launch,
-            "algorithmic_bytes_per_launch": int((trav_bytes + shade_bytes) / n_launch),
+            "algorithmic_bytes_per_launch": int(trav_bytes / n_launch),
             "counts_per_step": {"traversals": st2["traversals"], "box_tests": st2["box_tests"],
-                                "tri_tests": st2["tri_tests"], "shaded_hits": shaded},
+                                "tri_tests": st2["tri_tests"], "shaded_hits": shaded,
+                                "lean_traversals": st2["lean_traversals"], "lean_box_tests": st2["lean_box_tests"],
+                                "lean_tri_tests": st2["lean_tri_tests"]},
         }
     if not args.no_cpu_baseline and world == 1:
         cb = cpu_baseline(scene, p, args)

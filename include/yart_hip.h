@@ -137,6 +137,11 @@ typedef struct YartStats {
   uint64_t shaded_hits;      /* instrumented build only */
   double ms_extend, ms_shade, ms_connect, ms_gmon;   /* per-stage HIP-event time (wavefront pipeline) */
   uint32_t launches_extend, launches_connect;
+  /* the lean closest-hit kernel (k_wf_extend_fast) alone: HIP-event time, launches, and its share
+     of the exact test counters (instrumented build) — the roofline kernel of bench.py */
+  double ms_extend_lean;
+  uint64_t lean_traversals, lean_box_tests, lean_tri_tests;
+  uint32_t launches_extend_lean, reserved0;
 } YartStats;
 
 typedef struct YartScene YartScene;

@@ -104,7 +104,9 @@ class Stats(C.Structure):
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("waves", C.c_uint32),
                 ("launches_traverse", C.c_uint32), ("shaded_hits", C.c_uint64),
                 ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_connect", C.c_double),
-                ("ms_gmon", C.c_double), ("launches_extend", C.c_uint32), ("launches_connect", C.c_uint32)]
+                ("ms_gmon", C.c_double), ("launches_extend", C.c_uint32), ("launches_connect", C.c_uint32),
+                ("ms_extend_lean", C.c_double), ("lean_traversals", C.c_uint64), ("lean_box_tests", C.c_uint64),
+                ("lean_tri_tests", C.c_uint64), ("launches_extend_lean", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -35,6 +35,7 @@ struct HostImage {
   std::vector<LightDev> lights;
   std::vector<EnvDev> envs;
   std::vector<float> envData;
+  std::vector<uint32_t> envGuide;                  // CDF search guide tables (EnvDev::guideOffset)
   std::vector<uint32_t> infiniteLights, areaLights;
   std::vector<float> areaPowerCdf;
   std::vector<float> lut;                          // LutDev layout (incl. Sobol matrix bits)
@@ -51,6 +52,7 @@ struct HostImage {
     s.vTangent = vTangent.data(); s.vUV = vUV.data(); s.meshes = meshes.data(); s.nodes = nodes.data();
     s.materials = materials.data(); s.textures = textures.data(); s.texU8 = texU8.data();
     s.texF32 = texF32.data(); s.lights = lights.data(); s.envs = envs.data(); s.envData = envData.data();
+    s.envGuide = envGuide.data();
     s.infiniteLights = infiniteLights.data(); s.areaLights = areaLights.data();
     s.areaPowerCdf = areaPowerCdf.data(); s.lut = lut.data();
     s.nNodes = uint32_t(nodes.size()); s.nLights = nLights;
@@ -332,6 +334,21 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
       float theta0 = 0.0f * kPi, theta1 = 1.0f * kPi;
       e.surfaceArea = (phi1 - phi0) * (std::cos(theta0) - std::cos(theta1));
       ld.power = e.surfaceArea * kPi * l.radius * l.radius * (((0.0f + Lavg.x) + Lavg.y) + Lavg.z) / 3.0f;   // :206-209
+      {   // guide tables: G[j] = first index in [1, n) whose cdf is >= j / K (n if none), K = 2^k >= n
+        auto pow2ge = [](uint32_t n) { uint32_t k = 1; while (k < n) k <<= 1; return k; };
+        auto appendGuide = [&](const float* cdf, uint32_t n, uint32_t K) {
+          uint32_t idx = 1;
+          for (uint32_t j = 0; j <= K; j++) {
+            const float uj = float(j) / float(K);               // exact: K is a power of two <= 2^24
+            while (idx < n && cdf[idx] < uj) idx++;
+            im.envGuide.push_back(idx);
+          }
+        };
+        e.guideKw = pow2ge(w); e.guideKh = pow2ge(h);
+        e.guideOffset = uint32_t(im.envGuide.size());
+        appendGuide(im.envData.data() + e.margCdfOffset, h, e.guideKh);
+        for (uint32_t y = 0; y < h; y++) appendGuide(im.envData.data() + e.cdfOffset + size_t(y) * (w + 1), w, e.guideKw);
+      }
       ld.envOffset = uint32_t(im.envs.size());
       im.envs.push_back(e);
       im.infiniteLights.push_back(i);
@@ -360,6 +377,7 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
   if (im.lights.empty()) im.lights.push_back(LightDev{});
   if (im.envs.empty()) im.envs.push_back(EnvDev{});
   if (im.envData.empty()) im.envData.resize(1);
+  if (im.envGuide.empty()) im.envGuide.resize(1);
   if (im.infiniteLights.empty()) im.infiniteLights.push_back(0);
   if (im.areaLights.empty()) im.areaLights.push_back(0);
   if (im.areaPowerCdf.empty()) im.areaPowerCdf.push_back(0.0f);

@@ -22,19 +22,29 @@ YART_HD f3 sampleTriUniform(f2 u) {                       // sampling.hpp:54-64
   return mk3(b0, b1, 1.0f - b0 - b1);
 }
 
-// PiecewiseConstant1D::sample (sampling.cpp:5-34) over cdf[0..n], func[0..n-1]
+// PiecewiseConstant1D::sample (sampling.cpp:5-34) over cdf[0..n], func[0..n-1].
+// The reference's search is a lower bound over cdf[1..n-1]: A(u) = first index whose cdf is >= u
+// (n if none), which is monotone in u. With a guide table G[j] = A(j / K), K a power of two (so
+// that floor(u * K) is exact), A(u) lies in [G[j], G[j+1]] for j = floor(u * K): the same index is
+// found with ~1-2 dependent loads instead of log2(n).
 YART_HD float pc1dSample(const float* func, const float* cdf, uint32_t n, float integral, float mn,
-                         float mx, float u, float& pdf, uint32_t& offset) {
-  int64_t size = int64_t(n + 1) - 2, first = 1;
+                         float mx, float u, float& pdf, uint32_t& offset, const uint32_t* guide = nullptr,
+                         uint32_t K = 0) {
+  uint32_t first = 1, size = n - 1;                 // n >= 1
+  if (guide != nullptr) {
+    uint32_t j = u >= 0.0f ? uint32_t(u * float(K)) : 0u;     // NaN -> 0
+    if (j > K - 1u) j = K - 1u;                               // u < 1 for every sampler value
+    first = guide[j];
+    size = guide[j + 1u] - first;
+  }
   while (size > 0) {
-    int64_t half = size >> 1, middle = first + half;
+    const uint32_t half = size >> 1, middle = first + half;
     if (cdf[middle] < u) { first = middle + 1; size -= half + 1; }
     else size = half;
   }
-  int64_t o = first - 1;
-  if (o < 0) o = 0;
-  if (o > int64_t(n + 1) - 2) o = int64_t(n + 1) - 2;
-  offset = uint32_t(o);
+  uint32_t o = first - 1;                           // first >= 1
+  if (o > n - 1) o = n - 1;
+  offset = o;
   float du = u - cdf[o];
   // reference typo kept: normalises by cdf[0+1]-cdf[o]
   if (cdf[1] - cdf[o] > 0) du /= cdf[1] - cdf[o];
@@ -63,11 +73,13 @@ YART_HD LightSample envSample(const SceneDev& sc, const LightDev& l, f2 u) {   /
   float pdf1, pdf0;
   uint32_t ov, ou;
   // marginal over v with u.y, then conditional row with u.x (sampling.cpp:36-43)
+  const uint32_t* gm = e.guideKh ? sc.envGuide + e.guideOffset : nullptr;
   float d1 = pc1dSample(sc.envData + e.rowIntOffset, sc.envData + e.margCdfOffset, e.h, e.margIntegral,
-                        0.0f, 1.0f, u.y, pdf1, ov);
+                        0.0f, 1.0f, u.y, pdf1, ov, gm, e.guideKh);
   float rowInt = sc.envData[e.rowIntOffset + ov];
+  const uint32_t* gr = e.guideKw ? sc.envGuide + e.guideOffset + (e.guideKh + 1u) + size_t(ov) * (e.guideKw + 1u) : nullptr;
   float d0 = pc1dSample(sc.envData + e.funcOffset + ov * e.w, sc.envData + e.cdfOffset + ov * (e.w + 1),
-                        e.w, rowInt, 0.0f, 1.0f, u.x, pdf0, ou);
+                        e.w, rowInt, 0.0f, 1.0f, u.x, pdf0, ou, gr, e.guideKw);
   float pdf = pdf0 * pdf1;
   if (pdf == 0.0f) return emptyLightSample();
   f2 uv = mk2(d0, d1);

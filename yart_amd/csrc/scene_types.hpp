@@ -89,6 +89,9 @@ struct EnvDev {            // ImageInfiniteLight + PiecewiseConstant2D (light.cp
   uint32_t margCdfOffset;  // h+1 floats
   float margIntegral;
   float surfaceArea;       // light.cpp:192-196
+  // guide tables for the CDF searches (lights.hpp::pc1dSample): SceneDev::envGuide + guideOffset holds
+  // guideKh + 1 entries for the marginal CDF, then h rows of guideKw + 1 entries; 0 = none
+  uint32_t guideOffset, guideKw, guideKh, pad0;
 };
 
 struct CameraDev {         // core/camera.hpp:13-59
@@ -128,6 +131,7 @@ struct SceneDev {
   const LightDev* lights;
   const EnvDev* envs;
   const float* envData;
+  const uint32_t* envGuide;
   const uint32_t* infiniteLights;   // indices into lights
   const uint32_t* areaLights;       // indices into lights
   const float* areaPowerCdf;        // m_lightPowers, light-sampler.cpp:43-47

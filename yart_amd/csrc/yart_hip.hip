@@ -240,7 +240,7 @@ struct YartScene {
   DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32;
-  DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData;
+  DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide;
   DevBuf<uint32_t> infiniteLights, areaLights; DevBuf<float> areaPowerCdf; DevBuf<float> lut;
   // render scratch (grown on demand, reused across calls)
   DevBuf<uint32_t> pixels; DevBuf<float> L; DevBuf<uint32_t> cursor; DevBuf<unsigned long long> counters;
@@ -262,7 +262,7 @@ void uploadScene(YartScene& s) {
   s.triLight.upload(h.triLight); s.vPos.upload(h.vPos); s.vNormal.upload(h.vNormal);
   s.vTangent.upload(h.vTangent); s.vUV.upload(h.vUV); s.meshes.upload(h.meshes); s.nodes.upload(h.nodes);
   s.materials.upload(h.materials); s.textures.upload(h.textures); s.texU8.upload(h.texU8);
-  s.texF32.upload(h.texF32); s.lights.upload(h.lights); s.envs.upload(h.envs); s.envData.upload(h.envData);
+  s.texF32.upload(h.texF32); s.lights.upload(h.lights); s.envs.upload(h.envs); s.envData.upload(h.envData); s.envGuide.upload(h.envGuide);
   s.infiniteLights.upload(h.infiniteLights); s.areaLights.upload(h.areaLights);
   s.areaPowerCdf.upload(h.areaPowerCdf); s.lut.upload(h.lut);
   SceneDev d = h.view();       // counts and totals; pointers replaced below
@@ -270,7 +270,7 @@ void uploadScene(YartScene& s) {
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
   d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.lights = s.lights.p; d.envs = s.envs.p;
-  d.envData = s.envData.p; d.infiniteLights = s.infiniteLights.p; d.areaLights = s.areaLights.p;
+  d.envData = s.envData.p; d.envGuide = s.envGuide.p; d.infiniteLights = s.infiniteLights.p; d.areaLights = s.areaLights.p;
   d.areaPowerCdf = s.areaPowerCdf.p; d.lut = s.lut.p;
   s.dev = d;
 }
@@ -426,7 +426,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   }
 
   Timer tAll;
-  StageTimer tMega, tExtend, tShade, tConnect, tGmon;
+  StageTimer tMega, tExtend, tShade, tConnect, tGmon, tLean;
   uint32_t waves = 0;
   HIP_CHECK(hipEventRecord(tAll.a, stream));
 
@@ -489,7 +489,9 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           } else if (general) {
             hipLaunchKernelGGL(k_wf_extend<false>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
           } else {
+            tLean.begin(stream);
             hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
+            tLean.end(stream);
             hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
             hipLaunchKernelGGL(k_wf_reset_retry, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
           }
@@ -527,7 +529,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       HIP_CHECK(hipGetLastError());
       tGmon.end(stream);
       HIP_CHECK(hipStreamSynchronize(stream));
-      tMega.resolve(); tExtend.resolve(); tShade.resolve(); tConnect.resolve(); tGmon.resolve();
+      tMega.resolve(); tExtend.resolve(); tShade.resolve(); tConnect.resolve(); tGmon.resolve(); tLean.resolve();
     }
     remaining -= waveSamples;
     uint64_t next = (currentWave > 0 || waveSamples > 1) ? std::min<uint64_t>(waveSamples * 2, p.max_wave_samples) : 1;
@@ -549,6 +551,8 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     stats->ms_traverse = mega ? tMega.ms : tExtend.ms + tConnect.ms;
     stats->launches_traverse = mega ? tMega.launches : tExtend.launches + tConnect.launches;
     stats->ms_extend = tExtend.ms; stats->ms_shade = tShade.ms; stats->ms_connect = tConnect.ms; stats->ms_gmon = tGmon.ms;
+    stats->ms_extend_lean = tLean.ms; stats->launches_extend_lean = tLean.launches;
+    stats->lean_traversals = cnt[5]; stats->lean_box_tests = cnt[6]; stats->lean_tri_tests = cnt[7];
     stats->launches_extend = tExtend.launches; stats->launches_connect = tConnect.launches;
     stats->waves = waves;
     stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();

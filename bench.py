@@ -173,9 +173,18 @@ def main():
         achieved = trav_bytes / n_launch / (avg_ms * 1e-3) * 1e-9
         out["stage_ms_per_step"] = {k: round(last[k], 2) for k in
                                     ("ms_extend", "ms_extend_lean", "ms_connect", "ms_shade", "ms_gmon", "ms_device")}
+        traffic = None
+        if lean and (W, H, p["spp"], p["depth"], args.tex, args.sky) == (1920, 1080, 256, 8, 1024, 2048):
+            # memory-side bytes per launch of this kernel from the committed PMC passes (tools/pmc_hbm.sh)
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))
+                k = next(v for n, v in prof["kernels"].items() if n.startswith("k_wf_extend_fast"))
+                traffic = k["read_bytes_per_launch"] + k["write_bytes_per_launch"]
+            except (OSError, StopIteration, KeyError, ValueError):
+                traffic = None
         out["roofline"] = {
             "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
             "avg_launch_ms": round(avg_ms, 3), "launches_per_step": n_launch,
             "algorithmic_bytes_per_launch": int(trav_bytes / n_launch),
             "counts_per_step": {"traversals": st2["traversals"], "box_tests": st2["box_tests"],

@@ -108,7 +108,9 @@ static int doKat(Ctx& c, const params::Params& p, const std::string& outPath) {
     for (size_t m = 0; m < c.im.meshes.size(); m++) {
       const MeshDev& md = c.im.meshes[m];
       out.push_back(md.nNodes);
-      out.push_back(kat::fnv1a(c.im.bvhNodes.data() + md.nodeOffset, size_t(md.nNodes) * 32));
+      std::vector<BvhNode> plain(c.im.bvhNodes.begin() + md.nodeOffset, c.im.bvhNodes.begin() + md.nodeOffset + md.nNodes);
+      for (auto& n : plain) n.leftFirst &= kLinkIndexMask;       // the device image carries an extra flag bit
+      out.push_back(kat::fnv1a(plain.data(), size_t(md.nNodes) * 32));
       out.push_back(kat::fnv1a(c.im.bvhIndices[m].data(), c.im.bvhIndices[m].size() * 4));
     }
     w.u64("bvh", out);

@@ -9,7 +9,8 @@ if os.environ.get("YART_LIB"):          # experiment variant built by tools/buil
     api.LIB_PATH = os.path.join(ROOT, "yart_amd", "_variants", os.environ["YART_LIB"] + ".so")
     print("variant", os.environ["YART_LIB"], flush=True)
 w, h, spp = 960, 540, 64
-scene, p = scenes.sponza_class(w, h, spp, 8, tex=256, sky=256)
+TEX, SKY = int(os.environ.get("TEX", 256)), int(os.environ.get("SKY", 256))
+scene, p = scenes.sponza_class(w, h, spp, 8, tex=TEX, sky=SKY)
 ds = api.DeviceScene(scene, device=0)
 flags = [int(x) for x in sys.argv[1:]] or [0, 2]
 ref = None

@@ -157,8 +157,8 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
     const YartMeshDesc& m = d.meshes[mi];
     require(m.positions && m.normals && m.tangents && m.uvs && m.faces && m.n_faces > 0 && m.n_vertices > 0,
             "mesh: null array or empty mesh");
-    // traversal stack entries pack (leftFirst | span << 27): node and leaf indices < 2^27
-    require(m.n_faces < (1u << 26), "mesh: more than 2^26 triangles per mesh are not supported");
+    // traversal stack entries pack (index | alpha bit << 26 | span << 27): node and leaf indices < 2^26
+    require(m.n_faces < (1u << 25), "mesh: more than 2^25 triangles per mesh are not supported");
     for (uint32_t f = 0; f < m.n_faces; f++) {
       require(m.faces[4 * f] < m.n_vertices && m.faces[4 * f + 1] < m.n_vertices &&
               m.faces[4 * f + 2] < m.n_vertices, "mesh: vertex index out of range");
@@ -189,6 +189,20 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
       lt.material = m.faces[4 * t + 3];
       lt.matFlags = im.materials[lt.material].flags & (MAT_HAS_ALPHA | MAT_TRANSPARENT);
       im.leafTris.push_back(lt);
+    }
+    {   // alpha bit per BVH node, bottom-up (children are allocated after their parent)
+      std::vector<uint8_t> hasAlpha(b.nodes.size(), 0);
+      for (size_t n = b.nodes.size(); n-- > 0;) {
+        const BvhNode& bn = b.nodes[n];
+        if (bn.span > 0) {
+          for (uint32_t k = 0; k < bn.span; k++)
+            if (im.leafTris[md.leafOffset + bn.leftFirst + k].matFlags & MAT_HAS_ALPHA) hasAlpha[n] = 1;
+        } else {
+          hasAlpha[n] = hasAlpha[bn.leftFirst] | hasAlpha[bn.leftFirst + 1];
+        }
+        if (hasAlpha[n]) im.bvhNodes[md.nodeOffset + n].leftFirst |= kLinkAlphaBit;
+      }
+      md.hasAlpha = hasAlpha.empty() ? 0u : hasAlpha[0];
     }
     for (uint32_t f = 0; f < m.n_faces; f++) {
       u4 tv; tv.x = m.faces[4 * f]; tv.y = m.faces[4 * f + 1]; tv.z = m.faces[4 * f + 2]; tv.w = m.faces[4 * f + 3];

@@ -46,6 +46,12 @@ struct MaterialDev {       // bsdf/parametric.hpp:52-77
   float pad[2];
 };
 
+// BvhNode::leftFirst as stored for the device: bits 0..25 the reference's index (left child / first
+// leaf triangle), bit 26 set when the node's subtree contains a triangle with an alpha-tested
+// material (used by the lean shadow kernel to end occluded rays early, traverse.hpp).
+constexpr uint32_t kLinkIndexMask = (1u << 26) - 1u;
+constexpr uint32_t kLinkAlphaBit = 1u << 26;
+
 struct BvhNode {           // core/bvh.hpp:21-33 (32 bytes)
   float bmin[3];
   float bmax[3];
@@ -64,7 +70,8 @@ struct MeshDev {
   uint32_t leafOffset;     // into leafTris
   uint32_t triOffset;      // into triVerts / triLight
   uint32_t vertOffset;     // into vertex arrays
-  uint32_t nTris, nVerts, nNodes, pad;
+  uint32_t nTris, nVerts, nNodes;
+  uint32_t hasAlpha;       // some triangle of the mesh has an alpha-tested material
 };
 
 struct NodeDev {           // core/scene.hpp:11-64

@@ -118,7 +118,7 @@ __device__ __forceinline__ void traceWave(const SceneDev& sc, const SamplerConfi
           WF_PHASE(tally, 2);
           bool pop = true;
           if (d < hit.t) {                                      // inner node: test both children
-            const BvhNode* pair = nodes + leftFirst;
+            const BvhNode* pair = nodes + (leftFirst & kLinkIndexMask);
             const BvhNode c1 = pair[0], c2 = pair[1];
             YART_COUNT(nBox, 2);
             float d1, d2;
@@ -154,7 +154,7 @@ __device__ __forceinline__ void traceWave(const SceneDev& sc, const SamplerConfi
         const MeshDev& mesh = sc.meshes[meshIdx];
         for (uint32_t i = 0; i < span; i++) {
           WF_PHASE(tally, 3);
-          const LeafTri tr = leaves[leftFirst + i];
+          const LeafTri tr = leaves[(leftFirst & kLinkIndexMask) + i];
           YART_COUNT(nTri, 1);
           const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
           const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);

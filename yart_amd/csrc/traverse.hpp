@@ -172,11 +172,17 @@ YART_HD void interpUVN(const SceneDev& sc, const MeshDev& mesh, uint32_t tri, fl
 //    interleaving it with other lanes' inner steps;
 //  * a stack entry carries the far child's link word (leftFirst | span << 27) and entry
 //    distance, so a pop needs no dependent node fetch before the children can be loaded.
-constexpr uint32_t kSpanShift = 27;            // leftFirst < 2^27 (checked at scene build)
+constexpr uint32_t kSpanShift = 27;            // index < 2^26 (checked at scene build), bit 26 = kLinkAlphaBit
 template <bool NEE, int MODE = TRAV_GENERAL>
 YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t nodeIdx, const RayO& ray,
                           float tMin, HitRec& hit, f3& attenuation, const TravStack& stk,
-                          AlphaCtx& actx) {
+                          AlphaCtx& actx, bool occludedBefore = false) {
+  // Lean shadow kernel only (NEE && TRAV_FAST): once the ray is known to be occluded, the rest of
+  // the reference's walk can only matter through alpha tests (sampler draws); subtrees without
+  // alpha-tested triangles are skipped, and an alpha candidate hands the ray to the general kernel
+  // as before. Skipped subtrees could only have lowered hit.t, i.e. the walk visits a superset of
+  // the alpha candidates the reference tests: never a missed hand-over, at worst a spurious one.
+  constexpr bool kPrune = NEE && (MODE & TRAV_FAST);
   const BvhNode* nodes = sc.bvhNodes + mesh.nodeOffset;
   const LeafTri* leaves = sc.leafTris + mesh.leafOffset;
   uint32_t stackIdx = 0;
@@ -187,12 +193,14 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
   if (!testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) return false;
   uint32_t leftFirst = root.leftFirst, span = root.span;
   bool alive = true;
+  // "visit the current node": the reference's pop-cull, plus the pruning above
+#define YART_VISIT() (d < hit.t && (!kPrune || !(occludedBefore || didHit) || (leftFirst & kLinkAlphaBit)))
   while (alive) {
     // ---- inner nodes and pops, until a leaf must be tested
-    while (alive && !(span > 0 && d < hit.t)) {
+    while (alive && !(span > 0 && YART_VISIT())) {
       bool pop = true;
-      if (d < hit.t) {
-        const BvhNode* pair = nodes + leftFirst;           // siblings are adjacent: one 64-byte access
+      if (YART_VISIT()) {
+        const BvhNode* pair = nodes + (leftFirst & kLinkIndexMask);   // siblings are adjacent: one 64-byte access
         const BvhNode c1 = pair[0], c2 = pair[1];
         YART_COUNT(nBox, 2);
         float d1, d2;
@@ -223,7 +231,7 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
     if (!alive) break;
     // ---- leaf: triangles in index order
     for (uint32_t i = 0; i < span; i++) {
-      const LeafTri tr = leaves[leftFirst + i];
+      const LeafTri tr = leaves[(leftFirst & kLinkIndexMask) + i];
       YART_COUNT(nTri, 1);
       const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
       const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
@@ -242,7 +250,10 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
         if (v < 0.0f || u + v > 1.0f) break;
         const float t = dot(edge2, bEdge1) * invDet;
         if (t <= tMin || hit.t <= t) break;
-        if ((MODE & TRAV_FAST) && (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT))) {
+        // (a transparent surface is an ordinary hit for a closest-hit ray: only NEE rays treat it specially)
+        // and once a shadow ray is occluded its attenuation is never used)
+        if ((MODE & TRAV_FAST) &&
+            (tr.matFlags & ((NEE && !(occludedBefore || didHit)) ? (MAT_HAS_ALPHA | MAT_TRANSPARENT) : MAT_HAS_ALPHA))) {
           actx.deferred = true;
           return false;
         }
@@ -272,6 +283,7 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
     stackPop(stk, --stackIdx, link, d);
     leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
   }
+#undef YART_VISIT
   return didHit;
 }
 
@@ -343,8 +355,11 @@ YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& h
     YART_COUNT(nBox, 1);
     if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) { i = nd.skip; continue; }
     if (nd.mesh >= 0) {
-      didHit |= traverseMesh<NEE, MODE>(sc, sc.meshes[nd.mesh], i, ray, tMin, hit, attenuation, stk, actx);
-      if ((MODE & TRAV_FAST) && actx.deferred) return false;
+      const MeshDev& mesh = sc.meshes[nd.mesh];
+      if (!(NEE && (MODE & TRAV_FAST) && didHit && !mesh.hasAlpha)) {      // pruning, see traverseMesh
+        didHit |= traverseMesh<NEE, MODE>(sc, mesh, i, ray, tMin, hit, attenuation, stk, actx, didHit);
+        if ((MODE & TRAV_FAST) && actx.deferred) return false;
+      }
     }
     i++;
   }

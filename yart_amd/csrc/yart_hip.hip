@@ -713,6 +713,7 @@ int yart_hip_bvh_copy(YartScene* scene, uint32_t mesh, uint32_t* nodes_out, uint
     HIP_CHECK(hipSetDevice(scene->device));
     HIP_CHECK(hipMemcpy(nodes_out, scene->bvhNodes.p + m.nodeOffset, size_t(m.nNodes) * sizeof(BvhNode),
                         hipMemcpyDeviceToHost));
+    for (uint32_t n = 0; n < m.nNodes; n++) nodes_out[size_t(n) * 8 + 6] &= kLinkIndexMask;   // the reference's index only
     std::memcpy(indices_out, scene->host.bvhIndices[mesh].data(), size_t(m.nTris) * 4);
   });
 }

@@ -36,38 +36,70 @@ YART_HD TexTaps texTaps(const TexDev& t, f2 uv) {              // texture.cpp:21
 YART_HD float bilerp1(float a0, float a1, float b0, float b1, float u, float v) {   // math_base.hpp:46-59
   return ((a0 * (1.0f - u) * (1.0f - v) + a1 * (1.0f - u) * v) + b0 * u * (1.0f - v)) + b1 * u * v;
 }
-YART_HD float texel(const SceneDev& sc, const TexDev& t, uint32_t idx, uint32_t c) {
-  if (t.isFloat) return sc.texF32[t.offset + t.channels * idx + c];
-  float v = float(sc.texU8[t.offset + t.channels * idx + c]) / 255.0f;
+// One texel of a u8 texture as a word (channel c in byte c): one aligned load for 1/2/4-channel
+// texels (texture offsets are multiples of 4), two for 3-channel ones — instead of one byte
+// load per channel and tap (a divergent load costs the same address-unit time whatever its width).
+YART_HD uint32_t texelWord(const SceneDev& sc, const TexDev& t, uint32_t idx) {
+  const uint32_t b = t.offset + t.channels * idx;
+  if (t.channels == 4) return *reinterpret_cast<const uint32_t*>(sc.texU8 + b);
+  if (t.channels == 2) return *reinterpret_cast<const uint16_t*>(sc.texU8 + b);
+  if (t.channels == 1) return sc.texU8[b];
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(sc.texU8 + (b & ~3u));
+  const uint64_t v = uint64_t(w[0]) | (uint64_t(w[1]) << 32);
+  return uint32_t(v >> (8u * (b & 3u)));
+}
+YART_HD float texelChannel(const TexDev& t, uint32_t word, uint32_t c) {
+  float v = float((word >> (8u * c)) & 0xffu) / 255.0f;
   if (t.type == TEX_SRGB && c < 3) v = v * v;                  // texture.hpp:111-113
   return v;
 }
-YART_HD float texSampleChannel(const SceneDev& sc, const TexDev& t, const TexTaps& k, uint32_t c) {
-  return bilerp1(texel(sc, t, k.i00, c), texel(sc, t, k.i01, c), texel(sc, t, k.i10, c),
-                 texel(sc, t, k.i11, c), k.u, k.v);
+struct TexQuad { uint32_t w00, w01, w10, w11; };               // the four taps of a u8 texture
+YART_HD TexQuad texQuad(const SceneDev& sc, const TexDev& t, const TexTaps& k) {
+  TexQuad q;
+  q.w00 = texelWord(sc, t, k.i00); q.w01 = texelWord(sc, t, k.i01);
+  q.w10 = texelWord(sc, t, k.i10); q.w11 = texelWord(sc, t, k.i11);
+  return q;
+}
+YART_HD float texelF(const SceneDev& sc, const TexDev& t, uint32_t idx, uint32_t c) {
+  return sc.texF32[t.offset + t.channels * idx + c];
+}
+YART_HD float texSampleChannel(const SceneDev& sc, const TexDev& t, const TexTaps& k, const TexQuad& q, uint32_t c) {
+  if (t.isFloat)
+    return bilerp1(texelF(sc, t, k.i00, c), texelF(sc, t, k.i01, c), texelF(sc, t, k.i10, c), texelF(sc, t, k.i11, c),
+                   k.u, k.v);
+  return bilerp1(texelChannel(t, q.w00, c), texelChannel(t, q.w01, c), texelChannel(t, q.w10, c),
+                 texelChannel(t, q.w11, c), k.u, k.v);
+}
+YART_HD TexQuad texQuadOrZero(const SceneDev& sc, const TexDev& t, const TexTaps& k) {
+  if (t.isFloat) { TexQuad q; q.w00 = q.w01 = q.w10 = q.w11 = 0; return q; }
+  return texQuad(sc, t, k);
 }
 YART_HD f3 texSample3(const SceneDev& sc, int32_t tex, f2 uv) {
   const TexDev t = sc.textures[tex];
-  TexTaps k = texTaps(t, uv);
-  return mk3(texSampleChannel(sc, t, k, 0), texSampleChannel(sc, t, k, 1), texSampleChannel(sc, t, k, 2));
+  const TexTaps k = texTaps(t, uv);
+  const TexQuad q = texQuadOrZero(sc, t, k);
+  return mk3(texSampleChannel(sc, t, k, q, 0), texSampleChannel(sc, t, k, q, 1), texSampleChannel(sc, t, k, q, 2));
 }
 YART_HD f4 texSample4(const SceneDev& sc, int32_t tex, f2 uv) {
   const TexDev t = sc.textures[tex];
-  TexTaps k = texTaps(t, uv);
+  const TexTaps k = texTaps(t, uv);
+  const TexQuad q = texQuadOrZero(sc, t, k);
   f4 r;
-  r.x = texSampleChannel(sc, t, k, 0); r.y = texSampleChannel(sc, t, k, 1);
-  r.z = texSampleChannel(sc, t, k, 2); r.w = texSampleChannel(sc, t, k, 3);
+  r.x = texSampleChannel(sc, t, k, q, 0); r.y = texSampleChannel(sc, t, k, q, 1);
+  r.z = texSampleChannel(sc, t, k, q, 2); r.w = texSampleChannel(sc, t, k, q, 3);
   return r;
 }
 YART_HD f2 texSample2(const SceneDev& sc, int32_t tex, f2 uv) {
   const TexDev t = sc.textures[tex];
-  TexTaps k = texTaps(t, uv);
-  return mk2(texSampleChannel(sc, t, k, 0), texSampleChannel(sc, t, k, 1));
+  const TexTaps k = texTaps(t, uv);
+  const TexQuad q = texQuadOrZero(sc, t, k);
+  return mk2(texSampleChannel(sc, t, k, q, 0), texSampleChannel(sc, t, k, q, 1));
 }
 YART_HD float texSample1(const SceneDev& sc, int32_t tex, f2 uv) {
   const TexDev t = sc.textures[tex];
-  TexTaps k = texTaps(t, uv);
-  return texSampleChannel(sc, t, k, 0);
+  const TexTaps k = texTaps(t, uv);
+  const TexQuad q = texQuadOrZero(sc, t, k);
+  return texSampleChannel(sc, t, k, q, 0);
 }
 
 // ---------------------------------------------------------------------------

@@ -385,7 +385,7 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
   im.nLights = uint32_t(im.lights.size()); im.nInfinite = uint32_t(im.infiniteLights.size());
   im.nArea = uint32_t(im.areaLights.size()); im.nMaterials = uint32_t(im.materials.size());
   // never hand the kernels a null pointer for an empty table
-  if (im.texU8.empty()) im.texU8.resize(4);
+  im.texU8.insert(im.texU8.end(), 8, uint8_t(0));   // texelWord reads two aligned words for 3-channel texels
   if (im.texF32.empty()) im.texF32.resize(1);
   if (im.textures.empty()) im.textures.push_back(TexDev{});
   if (im.lights.empty()) im.lights.push_back(LightDev{});

@@ -136,29 +136,33 @@ struct GmonArgs {
   float* hdr;                  // RGBA32F, width * height
 };
 
+// 16 lanes per pixel (lane b < m sums bucket b in increasing sample order, as the reference's
+// accumulation does), 4 pixels per wave; the serial GMoN tail runs on one lane per pixel.
+constexpr int kGmonLanes = 16;
+static_assert(kGmonMax <= kGmonLanes, "one lane per bucket");
+constexpr int kGmonPixPerBlock = kBlock / kGmonLanes;
 __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
-  __shared__ float sAcc[kBlock / 64][kGmonMax][4];
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  const uint32_t pi = blockIdx.x * (kBlock / 64) + wv;
-  if (pi >= a.nPixels) return;           // whole wave exits together
+  __shared__ float sAcc[kGmonPixPerBlock][kGmonMax][4];
+  const uint32_t sub = threadIdx.x & (kGmonLanes - 1), lp = threadIdx.x / kGmonLanes;
+  const uint32_t pi = blockIdx.x * kGmonPixPerBlock + lp;
+  const bool valid = pi < a.nPixels;
   const int m = gmonBuckets(int32_t(a.spp));
-  if (int(lane) < m) {
+  if (valid && int(sub) < m) {
     f3 acc = mk3(0); uint32_t cnt = 0;
     const float* p = a.L + size_t(pi) * a.spp * 3;
-    for (uint32_t s = lane; s < a.spp; s += uint32_t(m)) {      // bucket k mod m, increasing k
+    for (uint32_t s = sub; s < a.spp; s += uint32_t(m)) {       // bucket k mod m, increasing k
       f3 v = mk3(p[s * 3], p[s * 3 + 1], p[s * 3 + 2]) * a.exposureScale;
       if (gmonAccepts(v)) { acc += v; cnt++; }
     }
-    sAcc[wv][lane][0] = acc.x; sAcc[wv][lane][1] = acc.y; sAcc[wv][lane][2] = acc.z;
-    sAcc[wv][lane][3] = __uint_as_float(cnt);
+    sAcc[lp][sub][0] = acc.x; sAcc[lp][sub][1] = acc.y; sAcc[lp][sub][2] = acc.z;
+    sAcc[lp][sub][3] = __uint_as_float(cnt);
   }
-  __builtin_amdgcn_wave_barrier();
-  __threadfence_block();
-  if (lane == 0) {
+  __syncthreads();
+  if (valid && sub == 0) {
     f3 acc[kGmonMax]; uint32_t cnt[kGmonMax];
     for (int b = 0; b < m; b++) {
-      acc[b] = mk3(sAcc[wv][b][0], sAcc[wv][b][1], sAcc[wv][b][2]);
-      cnt[b] = __float_as_uint(sAcc[wv][b][3]);
+      acc[b] = mk3(sAcc[lp][b][0], sAcc[lp][b][1], sAcc[lp][b][2]);
+      cnt[b] = __float_as_uint(sAcc[lp][b][3]);
     }
     f3 v = gmonFinish(acc, cnt, m);
     const uint32_t pk = a.pixels[pi];
@@ -525,7 +529,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       g.L = s.L.p; g.pixels = s.pixels.p + c0; g.nPixels = n; g.spp = uint32_t(waveSamples); g.width = W;
       g.exposureScale = cam.exposureScale; g.wCurrent = wCurrent; g.wWave = wWave; g.hdr = dOut;
       tGmon.begin(stream);
-      hipLaunchKernelGGL(k_gmon_blend, dim3((n + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, stream, g);
+      hipLaunchKernelGGL(k_gmon_blend, dim3((n + kGmonPixPerBlock - 1) / kGmonPixPerBlock), dim3(kBlock), 0, stream, g);
       HIP_CHECK(hipGetLastError());
       tGmon.end(stream);
       HIP_CHECK(hipStreamSynchronize(stream));

@@ -88,9 +88,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    # rehearsal knobs for a one-GPU box (never set by the driver): every rank on device 0, gloo instead of RCCL
+    backend = os.environ.get("YART_BENCH_BACKEND", "nccl")
+    if os.environ.get("YART_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     scene, p = scenes.sponza_class(args.width, args.height, args.spp, args.depth, tex=args.tex, sky=args.sky)
     W, H = p["size"]
@@ -105,7 +112,10 @@ def main():
         last.update(st)
         if world > 1:
             # non-owned tiles are exactly 0 on every rank -> the sum is the merged frame
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+            if backend == "nccl":
+                dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+            else:
+                dist.all_reduce(fb, op=dist.ReduceOp.SUM)      # gloo has no CUDA reduce
 
     def fence():
         if world > 1:

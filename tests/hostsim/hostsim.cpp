@@ -287,7 +287,102 @@ static int doRender(Ctx& c, const params::Params& p, const std::string& outPath)
   return 0;
 }
 
+// selftest: the table-driven forms of the device headers against their direct forms, on the host.
+//  * ZSobol index: SamplerTables entry + remaining digits == the reference's digit loop, for every
+//    log2spp / tile size combination, random pixels, dimensions and samples;
+//  * Sobol' dimension-1 byte tables == the bit loop;
+//  * CDF search with a guide table == the plain lower-bound search, on random and degenerate CDFs.
+static int doSelfTest() {
+  struct { uint64_t s = 0x5eed5eedull; uint32_t next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return uint32_t(s >> 32); } } rng;
+  uint64_t checked = 0;
+  std::vector<uint32_t> matrix52(52);
+  for (uint32_t k = 0; k < 52; k++) matrix52[k] = sobolDim1Column(k);
+  std::vector<uint32_t> byteTab(8 * 256);
+  for (uint32_t k = 0; k < 8 * 256; k++) {
+    uint32_t b = k >> 8, v = k & 255u, x = 0;
+    for (uint32_t j = 0; j < 8; j++) if (((v >> j) & 1u) && 8 * b + j < 52) x ^= matrix52[8 * b + j];
+    byteTab[k] = x;
+  }
+  for (uint32_t spp : {1u, 2u, 3u, 4u, 8u, 12u, 16u, 32u, 48u, 64u, 128u, 256u, 512u, 1024u}) {
+    for (uint32_t tile : {8u, 64u, 100u, 512u, 4096u}) {
+      SamplerConfig cfg = makeSamplerConfig(spp, tile);
+      if (uint64_t(spp) > (1ull << cfg.log2spp)) continue;      // the renderer disables the tables here
+      const uint32_t dims = 40, nPix = 24;
+      std::vector<uint32_t> px(nPix), py(nPix);
+      std::vector<uint64_t> entries(size_t(dims) * nPix), hash(dims + 3);
+      for (uint32_t i = 0; i < nPix; i++) { px[i] = rng.next() % 4000u; py[i] = rng.next() % 3000u; }
+      for (uint32_t d = 0; d < dims; d++)
+        for (uint32_t i = 0; i < nPix; i++) entries[size_t(d) * nPix + i] = samplerTableEntry(cfg, encodeMorton2(px[i], py[i]), d);
+      for (uint32_t d = 0; d < dims + 3; d++) hash[d] = hashDim(d);
+      SamplerConfig tcfg = cfg;
+      tcfg.tab.entries = entries.data(); tcfg.tab.hash = hash.data(); tcfg.tab.sobol1 = byteTab.data();
+      tcfg.tab.dims = dims; tcfg.tab.stride = nPix;
+      for (uint32_t i = 0; i < nPix; i++) {
+        for (uint32_t rep = 0; rep < 40; rep++) {
+          Sampler a, b;
+          startPixelSample(a, cfg, px[i], py[i], rng.next() % spp);
+          a.dim = rng.next() % (dims + 6);                      // also beyond the table: fallback
+          b = a; b.pix = i;
+          if (getSampleIndexDirect(a, cfg) != getSampleIndex(b, tcfg)) {
+            std::fprintf(stderr, "selftest: sample index mismatch spp=%u tile=%u dim=%u\n", spp, tile, a.dim);
+            return 3;
+          }
+          Sampler a2 = a, b2 = b;
+          f2 u0 = get2D(a2, cfg, matrix52.data()), u1 = get2D(b2, tcfg, matrix52.data());
+          float v0 = get1D(a2, cfg), v1 = get1D(b2, tcfg);
+          if (std::memcmp(&u0, &u1, sizeof(u0)) != 0 || std::memcmp(&v0, &v1, 4) != 0 || a2.dim != b2.dim) {
+            std::fprintf(stderr, "selftest: sample value mismatch spp=%u tile=%u dim=%u\n", spp, tile, a.dim);
+            return 3;
+          }
+          checked++;
+        }
+      }
+    }
+  }
+  // CDF search
+  for (uint32_t n : {1u, 2u, 3u, 7u, 64u, 100u, 1000u}) {
+    for (int kind = 0; kind < 4; kind++) {
+      std::vector<float> func(n), cdf(n + 1);
+      for (uint32_t k = 0; k < n; k++) {
+        float f = float(rng.next() % 1000u) / 1000.0f;
+        if (kind == 1) f = (k % 5 == 0) ? f : 0.0f;             // long zero runs (flat CDF segments)
+        if (kind == 2) f = (k == n / 2) ? 1.0f : 0.0f;          // a single spike
+        if (kind == 3) f = 0.0f;                                // all zero -> uniform CDF
+        func[k] = f;
+      }
+      cdf[0] = 0.0f;
+      for (uint32_t k = 1; k <= n; k++) cdf[k] = cdf[k - 1] + func[k - 1] / float(n);
+      const float integral = cdf[n];
+      for (uint32_t k = 1; k <= n; k++) cdf[k] = integral == 0.0f ? float(k) / float(n) : cdf[k] / integral;
+      uint32_t K = 1; while (K < n) K <<= 1;
+      std::vector<uint32_t> guide;
+      uint32_t idx = 1;
+      for (uint32_t j = 0; j <= K; j++) {
+        const float uj = float(j) / float(K);
+        while (idx < n && cdf[idx] < uj) idx++;
+        guide.push_back(idx);
+      }
+      for (uint32_t rep = 0; rep < 4000; rep++) {
+        float u = float(rng.next() & 0xffffffu) * 0x1p-24f;
+        if (rep % 7 == 0) u = cdf[rng.next() % (n + 1)];        // exactly on a CDF value
+        if (u >= 1.0f) u = kOneMinusEpsilon;
+        float pdf0, pdf1; uint32_t o0, o1;
+        float x0 = pc1dSample(func.data(), cdf.data(), n, integral, 0.0f, 1.0f, u, pdf0, o0);
+        float x1 = pc1dSample(func.data(), cdf.data(), n, integral, 0.0f, 1.0f, u, pdf1, o1, guide.data(), K);
+        if (o0 != o1 || std::memcmp(&x0, &x1, 4) != 0 || std::memcmp(&pdf0, &pdf1, 4) != 0) {
+          std::fprintf(stderr, "selftest: guided CDF search mismatch n=%u kind=%d u=%a (%u vs %u)\n", n, kind, u, o0, o1);
+          return 3;
+        }
+        checked++;
+      }
+    }
+  }
+  std::printf("{\"selftest\": \"ok\", \"checked\": %llu}\n", (unsigned long long) checked);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 2 && std::string(argv[1]) == "selftest") return doSelfTest();
   if (argc != 5) {
     std::fprintf(stderr, "usage: hostsim kat|render <scene.yscn> <params.txt> <out>\n");
     return 1;

@@ -55,3 +55,13 @@ def test_embedded_luts_match_reference_tables():
     a = np.fromfile(os.path.join(GOLDEN, "ref_tables.bin"), np.uint32)
     b = np.fromfile(os.path.join(ROOT, "yart_amd", "data", "ggx_luts.bin"), np.uint32)
     assert np.array_equal(a, b)
+
+
+def test_table_forms_equal_direct_forms(hostsim):
+    """SamplerTables (hoisted ZSobol digits, hash table, Sobol' byte tables) and the guided CDF
+    search reproduce the direct forms bit for bit — every log2spp / tile combination, dimensions
+    inside and beyond the table, random and degenerate CDFs (hostsim `selftest`)."""
+    import json
+    r = subprocess.run([hostsim, "selftest"], check=True, capture_output=True, text=True)
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["selftest"] == "ok" and info["checked"] > 100000

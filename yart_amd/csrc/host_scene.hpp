@@ -36,6 +36,7 @@ struct HostImage {
   std::vector<EnvDev> envs;
   std::vector<float> envData;
   std::vector<uint32_t> envGuide;                  // CDF search guide tables (EnvDev::guideOffset)
+  std::vector<f4> nodeWorld;                       // conservative world-space node boxes (traverse.hpp)
   std::vector<uint32_t> infiniteLights, areaLights;
   std::vector<float> areaPowerCdf;
   std::vector<float> lut;                          // LutDev layout (incl. Sobol matrix bits)
@@ -52,7 +53,7 @@ struct HostImage {
     s.vTangent = vTangent.data(); s.vUV = vUV.data(); s.meshes = meshes.data(); s.nodes = nodes.data();
     s.materials = materials.data(); s.textures = textures.data(); s.texU8 = texU8.data();
     s.texF32 = texF32.data(); s.lights = lights.data(); s.envs = envs.data(); s.envData = envData.data();
-    s.envGuide = envGuide.data();
+    s.envGuide = envGuide.data(); s.nodeWorld = nodeWorld.data();
     s.infiniteLights = infiniteLights.data(); s.areaLights = areaLights.data();
     s.areaPowerCdf = areaPowerCdf.data(); s.lut = lut.data();
     s.nNodes = uint32_t(nodes.size()); s.nLights = nLights;
@@ -269,6 +270,41 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
     uint32_t j = i + 1;
     while (j < nn && im.nodes[j].depth > nd.depth) j++;
     nd.skip = j;
+  }
+
+  // Conservative world-space box per node: the node's local box pushed through its forward chain in
+  // double precision, then padded far beyond the rounding of the reference's object-space test
+  // (2e-3 + 1e-4 * |coordinate|; the boxes themselves already carry the reference's +-0.001).
+  // The device tests it first (world ray, no transform) and runs the reference's exact test only on
+  // the survivors, so it can only skip work the exact test would also have skipped.
+  im.nodeWorld.resize(size_t(nn) * 2);
+  for (uint32_t i = 0; i < nn; i++) {
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    const NodeDev& nd = im.nodes[i];
+    bool finite = true;
+    for (int corner = 0; corner < 8; corner++) {
+      double p[3] = {(corner & 4) ? nd.bmax[0] : nd.bmin[0], (corner & 2) ? nd.bmax[1] : nd.bmin[1],
+                     (corner & 1) ? nd.bmax[2] : nd.bmin[2]};
+      for (int32_t a = int32_t(i); a >= 0; a = im.nodes[a].parent) {
+        const float* m = im.nodes[a].xf.fwd;                    // row-major 4x4, points: w = 1
+        double q[3];
+        for (int r = 0; r < 3; r++) q[r] = double(m[4 * r]) * p[0] + double(m[4 * r + 1]) * p[1] + double(m[4 * r + 2]) * p[2] + double(m[4 * r + 3]);
+        p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+      }
+      for (int c = 0; c < 3; c++) {
+        if (!std::isfinite(p[c])) finite = false;
+        mn[c] = std::min(mn[c], p[c]); mx[c] = std::max(mx[c], p[c]);
+      }
+    }
+    f4 lo, hi;
+    float* l = &lo.x; float* h = &hi.x;
+    for (int c = 0; c < 3; c++) {
+      const double pad = 2e-3 + 1e-4 * std::max(std::fabs(mn[c]), std::fabs(mx[c]));
+      l[c] = finite ? float(mn[c] - pad) : -kInf;               // float() rounds to nearest: the pad dwarfs it
+      h[c] = finite ? float(mx[c] + pad) : kInf;
+    }
+    lo.w = hi.w = 0.0f;
+    im.nodeWorld[2 * i] = lo; im.nodeWorld[2 * i + 1] = hi;
   }
 
   // ---- lights (light.cpp, light-sampler.cpp:32-50) ------------------------------

@@ -139,6 +139,7 @@ struct SceneDev {
   const EnvDev* envs;
   const float* envData;
   const uint32_t* envGuide;
+  const f4* nodeWorld;       // 2 per scene node: padded WORLD-space AABB of the node's subtree (min, max)
   const uint32_t* infiniteLights;   // indices into lights
   const uint32_t* areaLights;       // indices into lights
   const float* areaPowerCdf;        // m_lightPowers, light-sampler.cpp:43-47

@@ -346,6 +346,15 @@ YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& h
     if ((MODE & TRAV_IDENTITY) || (nd.pad[0] & 1u)) {
       if (!rayIsWorld) { ray = makeRay(o + 0.0f, d + 0.0f); rayIsWorld = true; }
     } else if (!(MODE & TRAV_IDENTITY)) {
+      // transformed node: conservative cull in world space first (host_scene.hpp: padded world box,
+      // here a padded [0, hit.t] interval) — no 4x4 products, no slab set-up for the instances a ray
+      // passes by; the reference's own object-space test follows for the survivors
+      if (!rayIsWorld) { ray = makeRay(o + 0.0f, d + 0.0f); rayIsWorld = true; }
+      const f4 wlo = sc.nodeWorld[2u * i], whi = sc.nodeWorld[2u * i + 1u];
+      const float wmin[3] = {wlo.x, wlo.y, wlo.z}, wmax[3] = {whi.x, whi.y, whi.z};
+      float dw;
+      YART_COUNT(nBox, 1);
+      if (!testBox(ray, 0.0f, hit.t + (fabsf(hit.t) * 1e-4f + 1e-3f), wmin, wmax, dw)) { i = nd.skip; continue; }
       f3 oo, od;
       nodeObjectRay(sc, i, nd, o, d, cache, oo, od);
       ray = makeRay(oo, od);

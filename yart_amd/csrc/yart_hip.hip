@@ -244,7 +244,7 @@ struct YartScene {
   DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32;
-  DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide;
+  DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld;
   DevBuf<uint32_t> infiniteLights, areaLights; DevBuf<float> areaPowerCdf; DevBuf<float> lut;
   // render scratch (grown on demand, reused across calls)
   DevBuf<uint32_t> pixels; DevBuf<float> L; DevBuf<uint32_t> cursor; DevBuf<unsigned long long> counters;
@@ -266,7 +266,7 @@ void uploadScene(YartScene& s) {
   s.triLight.upload(h.triLight); s.vPos.upload(h.vPos); s.vNormal.upload(h.vNormal);
   s.vTangent.upload(h.vTangent); s.vUV.upload(h.vUV); s.meshes.upload(h.meshes); s.nodes.upload(h.nodes);
   s.materials.upload(h.materials); s.textures.upload(h.textures); s.texU8.upload(h.texU8);
-  s.texF32.upload(h.texF32); s.lights.upload(h.lights); s.envs.upload(h.envs); s.envData.upload(h.envData); s.envGuide.upload(h.envGuide);
+  s.texF32.upload(h.texF32); s.lights.upload(h.lights); s.envs.upload(h.envs); s.envData.upload(h.envData); s.envGuide.upload(h.envGuide); s.nodeWorld.upload(h.nodeWorld);
   s.infiniteLights.upload(h.infiniteLights); s.areaLights.upload(h.areaLights);
   s.areaPowerCdf.upload(h.areaPowerCdf); s.lut.upload(h.lut);
   SceneDev d = h.view();       // counts and totals; pointers replaced below
@@ -274,7 +274,7 @@ void uploadScene(YartScene& s) {
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
   d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.lights = s.lights.p; d.envs = s.envs.p;
-  d.envData = s.envData.p; d.envGuide = s.envGuide.p; d.infiniteLights = s.infiniteLights.p; d.areaLights = s.areaLights.p;
+  d.envData = s.envData.p; d.envGuide = s.envGuide.p; d.nodeWorld = s.nodeWorld.p; d.infiniteLights = s.infiniteLights.p; d.areaLights = s.areaLights.p;
   d.areaPowerCdf = s.areaPowerCdf.p; d.lut = s.lut.p;
   s.dev = d;
 }

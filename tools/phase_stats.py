@@ -6,9 +6,11 @@ from yart_amd import api, scenes
 api.LIB_COUNT_PATH = os.path.join(ROOT, "yart_amd", "libyart_hip_stats.so")
 scene, p = scenes.sponza_class(960, 540, 64, 8, tex=256, sky=256)
 ds = api.DeviceScene(scene, device=0, instrumented=True)
-img, st = ds.render(p, flags=2)
+flags = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+img, st = ds.render(p, flags=flags)
 c = ds.debug_counters()
-names = ["outer", "walk-node", "inner/pop", "tri", "slowpath", "leaf", "refill"]
+names = ["outer", "walk-node", "inner/pop", "tri", "slowpath", "leaf", "refill"] if flags == 2 else \
+        ["inner/pop", "tri", "leaf-visit", "walk-step", "mask-box", "outer-round", "refill"]
 print("ms extend %.1f connect %.1f" % (st["ms_extend"], st["ms_connect"]))
 for k, n in enumerate(names):
     it, act = c[8 + 2 * k], c[9 + 2 * k]

@@ -303,7 +303,12 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
       l[c] = finite ? float(mn[c] - pad) : -kInf;               // float() rounds to nearest: the pad dwarfs it
       h[c] = finite ? float(mx[c] + pad) : kInf;
     }
-    lo.w = hi.w = 0.0f;
+    // .w of the pair: bits of the node's pre-order subtree [i, skip) as a 64-bit mask (scenes of up to
+    // 64 nodes; trace_lean.hpp keeps a per-ray candidate mask), else 0
+    uint64_t sub = 0;
+    if (nn <= 64) for (uint32_t k = i; k < nd.skip; k++) sub |= 1ull << k;
+    const uint32_t subLo = uint32_t(sub), subHi = uint32_t(sub >> 32);
+    std::memcpy(&lo.w, &subLo, 4); std::memcpy(&hi.w, &subHi, 4);
     im.nodeWorld[2 * i] = lo; im.nodeWorld[2 * i + 1] = hi;
   }
 

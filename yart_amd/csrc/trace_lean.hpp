@@ -1,0 +1,257 @@
+// trace_lean.hpp — lean traversal with in-wave ray replacement (device only).
+//
+// Per ray this is traverse.hpp's TRAV_FAST walk, operation for operation (same scene-node
+// order, same ordered BVH traversal, same leaf order, alpha / transparent candidates hand the
+// ray to the general kernel). What changes is how a 64-wide wave is kept busy: bounced rays have
+// heavy-tailed traversal lengths (mean ≈ 37 inner steps, the slowest of 64 ≈ 170), so in the
+// one-ray-per-lane kernel 70-80 % of the lanes wait for the wave's slowest ray. Here
+//
+//   (A) lanes whose ray has finished take new queue entries as soon as at least kRefill lanes
+//       are out of the BVH (one ballot + one atomicAdd per refill),
+//   (B) the scene-graph walk of all lanes that stand between two meshes runs to the point where
+//       each of them has entered a mesh or finished its ray,
+//   (C) "while-while": inner / pop steps until every lane inside a BVH stands at a leaf it must
+//       test, then the leaves; repeated until fewer than 64 - kRefill lanes are inside a BVH.
+//
+// Lane state is small (object-space ray, hit, BVH cursor, stack index): the world ray of a lane
+// that re-enters the walk after a transformed node is re-read from the path state.
+#pragma once
+#if defined(__HIPCC__)
+#include "traverse.hpp"
+
+namespace yart_hip {
+
+constexpr uint32_t kLeanRefill = 16;      // refill when at least this many lanes are outside a BVH
+#ifndef YART_LEAN_INNER_MIN
+#define YART_LEAN_INNER_MIN 16
+#endif
+constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;   // leave the inner loop when fewer lanes than this still step
+
+struct LeanRay { f3 o, d; float tMax; };
+
+// Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)
+// Commit(slot, hit, didHit); Retry(pred, slot) appends to the retry queue (wave-wide call)
+template <bool NEE, int MODE, class Fetch, class Commit, class Retry>
+__device__ __forceinline__ void traceLean(const SceneDev& sc, const TravStack& stk, const uint32_t* queue,
+                                          uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
+                                          Retry retry, WfTally& tally) {
+  static_assert(MODE & TRAV_FAST, "lean tracer: no alpha code");
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long laneLt = (1ull << lane) - 1ull;
+  const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+  const float tMin = 0.001f;
+  bool has = false, inMesh = false, exhausted = false, firstFill = true, pendingRetry = false;
+  bool didHit = false, meshDidHit = false, rayIsWorld = false;
+  uint32_t slot = 0, nodeI = 0, leftFirst = 0, span = 0, stackIdx = 0;
+  float d = 0.0f;
+  RayO ray = makeRay(mk3(0.0f), mk3(1.0f));
+  HitRec hit; hit.t = 0; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
+  const BvhNode* nodes = sc.bvhNodes;
+  const LeafTri* leaves = sc.leafTris;
+  bool meshHasAlpha = false;
+  // scene nodes this ray can reach at all: bit n survives if the padded world box of n and of all
+  // its ancestors is hit within [0, tMax] (conservative, see traverseScene); requires nNodes <= 64
+  unsigned long long cand = 0;
+#if defined(YART_COUNT_TRAVERSAL)
+  AlphaCtx actx; actx.sampler = nullptr;     // only its counters are used (YART_COUNT)
+#endif
+
+#define LEAN_VISIT() (d < hit.t && (!NEE || !(didHit || meshDidHit) || (leftFirst & kLinkAlphaBit)))
+  for (;;) {
+    // ------------------------------------------------------------------ (A) retry hand-over + refill
+    retry(pendingRetry, slot);
+    pendingRetry = false;
+    if (has) WF_PHASE(tally, 5);                               // outer rounds / lanes holding a ray
+    const unsigned long long idle = __ballot(!has);
+    const uint32_t nIdle = uint32_t(__popcll(idle));
+    if (nIdle == 64u && exhausted) break;
+    if (!exhausted && nIdle >= kLeanRefill) {
+      uint32_t base;
+      if (firstFill) {                                          // by wave index, no atomic
+        firstFill = false;
+        base = waveId * 64u;
+        if (nWaves * 64u >= count) exhausted = true;
+      } else {
+        const int leader = __ffsll((long long) idle) - 1;
+        base = 0;
+        if (int(lane) == leader) base = atomicAdd(cursor, nIdle);
+        base = nWaves * 64u + __shfl(base, leader);
+        if (base + nIdle >= count) exhausted = true;           // wave-uniform
+      }
+      if (!has) {
+        const uint32_t k = base + uint32_t(__popcll(idle & laneLt));
+        if (k < count) {
+          WF_PHASE(tally, 6);                                   // refills / rays fetched
+          slot = queue[k];
+          const LeanRay r = fetch(slot);
+          ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true;
+          hit.t = r.tMax; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
+          has = true; inMesh = false; nodeI = 0; didHit = false;
+          YART_COUNT(nTrav, 1);
+          cand = ~0ull;
+        }
+      }
+      // candidate masks of the new rays: one pass over the node boxes (wave-uniform addresses)
+      const bool fresh = has && cand == ~0ull;
+      if (fresh) cand = sc.nNodes >= 64u ? ~0ull : ((1ull << sc.nNodes) - 1ull);
+      for (uint32_t n = 0; n < sc.nNodes; n++) {
+        const f4 wlo = sc.nodeWorld[2u * n], whi = sc.nodeWorld[2u * n + 1u];
+        if (fresh && ((cand >> n) & 1ull)) {
+          WF_PHASE(tally, 4);                                   // candidate-mask box tests
+          const float wmin[3] = {wlo.x, wlo.y, wlo.z}, wmax[3] = {whi.x, whi.y, whi.z};
+          float dw;
+          YART_COUNT(nBox, 1);
+          if (!testBox(ray, 0.0f, hit.t + (fabsf(hit.t) * 1e-4f + 1e-3f), wmin, wmax, dw))
+            cand &= ~((unsigned long long) __builtin_bit_cast(uint32_t, wlo.w) |
+                      ((unsigned long long) __builtin_bit_cast(uint32_t, whi.w) << 32));
+        }
+      }
+    }
+
+    // ------------------------------------------------------------------ (B) scene-graph walk
+    {
+      while (has && !inMesh) {                                  // (lanes leave this loop one by one)
+        WF_PHASE(tally, 3);                                     // walk steps
+        const unsigned long long rest = nodeI < 64u ? (cand >> nodeI) : 0ull;
+        if (rest == 0ull) {                                     // testNode of the root has returned
+          commit(slot, hit, didHit);
+          has = false;
+        } else {
+          nodeI += uint32_t(__builtin_ctzll(rest));             // next node the ray can reach
+          const NodeDev& nd = sc.nodes[nodeI];
+          bool skip = false;
+          if (!((MODE & TRAV_IDENTITY) || (nd.pad[0] & 1u))) {
+            // transformed node (its padded world box is known to be hit): the exact object-space ray
+            const LeanRay r = fetch(slot);                      // the exact world ray (ray.o/d carry +0.0f)
+            f3 oo, od;
+            objectRay(sc, nodeI, r.o, r.d, oo, od);
+            ray = makeRay(oo, od); rayIsWorld = false;
+          } else if (!rayIsWorld) {
+            const LeanRay r = fetch(slot); ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true;
+          }
+          float dd;
+          if (!skip) {
+            YART_COUNT(nBox, 1);
+            if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) skip = true;
+          }
+          if (skip) nodeI = nd.skip;                            // (bits of the subtree may remain set: skipped by index)
+          else {
+            bool entered = false;
+            if (nd.mesh >= 0) {
+              const MeshDev& mesh = sc.meshes[nd.mesh];
+              if (!(NEE && didHit && !mesh.hasAlpha)) {         // pruning of occluded shadow rays (traverse.hpp)
+                nodes = sc.bvhNodes + mesh.nodeOffset;
+                leaves = sc.leafTris + mesh.leafOffset;
+                meshHasAlpha = mesh.hasAlpha != 0;
+                const BvhNode root = nodes[0];
+                YART_COUNT(nBox, 1);
+                if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
+                  inMesh = true; entered = true;
+                  leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
+                }
+              }
+            }
+            if (!entered) nodeI++;
+          }
+        }
+      }
+    }
+
+    // ------------------------------------------------------------------ (C) BVH traversal, while-while
+    for (;;) {
+      // inner nodes and pops until every lane inside a BVH stands at a leaf it must test
+      {
+        while (inMesh && !(span > 0 && LEAN_VISIT())) {
+          WF_PHASE(tally, 0);                                   // inner / pop steps
+          bool pop = true;
+          if (LEAN_VISIT()) {
+            const BvhNode* pair = nodes + (leftFirst & kLinkIndexMask);
+            const BvhNode c1 = pair[0], c2 = pair[1];
+            YART_COUNT(nBox, 2);
+            float d1, d2;
+            bool hit1, hit2;
+            testBox2(ray, tMin, hit.t, c1, c2, hit1, hit2, d1, d2);
+            if (hit1 || hit2) {
+              const bool firstNear = hit1 && !(hit2 && d1 > d2);
+              if (hit1 && hit2)
+                stackPush(stk, stackIdx++, firstNear ? (c2.leftFirst | (c2.span << kSpanShift))
+                                                     : (c1.leftFirst | (c1.span << kSpanShift)),
+                          firstNear ? d2 : d1);
+              d = firstNear ? d1 : d2;
+              leftFirst = firstNear ? c1.leftFirst : c2.leftFirst;
+              span = firstNear ? c1.span : c2.span;
+              pop = false;
+            }
+          }
+          if (pop) {
+            if (stackIdx == 0) { inMesh = false; didHit |= meshDidHit; nodeI++; }     // testBVH returns
+            else {
+              uint32_t link;
+              stackPop(stk, --stackIdx, link, d);
+              leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
+            }
+          }
+          // the stragglers of the inner phase do not hold up the lanes waiting at their leaves:
+          // they step again after the leaf phase, together with the lanes that come back from it
+          if (uint32_t(__popcll(__ballot(true))) < kLeanInnerMin) break;
+        }
+      }
+      // leaves: triangles in index order
+      if (inMesh && span > 0 && LEAN_VISIT()) {
+        WF_PHASE(tally, 2);                                     // leaf visits
+        const uint32_t first = leftFirst & kLinkIndexMask;
+        for (uint32_t i = 0; i < span; i++) {
+          WF_PHASE(tally, 1);                                   // triangle tests
+          const LeafTri tr = leaves[first + i];
+          YART_COUNT(nTri, 1);
+          const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
+          const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
+          const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
+          bool accepted = false;
+          do {
+            const f3 rayEdge2 = cross(ray.d, edge2);
+            const float det = dot(edge1, rayEdge2);
+            if (double(fabsf(det)) < 1e-12) break;
+            const float invDet = 1.0f / det;
+            const f3 b = ray.o - p0;
+            const float u = dot(b, rayEdge2) * invDet;
+            if (u < 0.0f || u > 1.0f) break;
+            const f3 bEdge1 = cross(b, edge1);
+            const float v = dot(ray.d, bEdge1) * invDet;
+            if (v < 0.0f || u + v > 1.0f) break;
+            const float t = dot(edge2, bEdge1) * invDet;
+            if (t <= tMin || hit.t <= t) break;
+            if (tr.matFlags & ((NEE && !(didHit || meshDidHit)) ? (MAT_HAS_ALPHA | MAT_TRANSPARENT) : MAT_HAS_ALPHA)) {
+              pendingRetry = true;                              // the general kernel traces this ray again
+              break;
+            }
+            hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeI;
+            hit.backSide = det < 0 ? 1u : 0u;
+            accepted = true;
+          } while (false);
+          if (pendingRetry) break;
+          meshDidHit |= accepted;
+          if (NEE && meshDidHit) break;
+        }
+        if (pendingRetry) { has = false; inMesh = false; }
+        else if (stackIdx == 0) { inMesh = false; didHit |= meshDidHit; nodeI++; }
+        else {
+          uint32_t link;
+          stackPop(stk, --stackIdx, link, d);
+          leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
+        }
+      }
+      if (uint32_t(__popcll(__ballot(inMesh))) < 64u - kLeanRefill + 1u) break;
+    }
+  }
+#undef LEAN_VISIT
+  (void)meshHasAlpha;
+#if defined(YART_COUNT_TRAVERSAL)
+  tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
+#else
+  (void)tally;
+#endif
+}
+
+}  // namespace yart_hip
+#endif  // __HIPCC__

@@ -31,6 +31,7 @@
 #include "scene_file.hpp"
 #include "wavefront.hpp"
 #include "trace_wave.hpp"
+#include "trace_lean.hpp"
 
 using namespace yart_hip;
 
@@ -400,8 +401,11 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const bool general = (p.flags & YART_FLAG_GENERAL_TRACE) != 0;
   const bool waveTrace = (p.flags & YART_FLAG_WAVE_TRACE) != 0;
   const bool ident = s.host.allIdentity;
-  auto kExtendFast = ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
-  auto kShadowFast = ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>;
+  const bool refill = (p.flags & YART_FLAG_LEAN_REFILL) != 0 && s.host.nodes.size() <= 64;   // per-ray node mask
+  auto kExtendFast = refill ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_lean<TRAV_FAST>)
+                            : (ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>);
+  auto kShadowFast = refill ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_lean<TRAV_FAST>)
+                            : (ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>);
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
   const int gridExtendFast = persistentGrid(s, reinterpret_cast<const void*>(kExtendFast), 8);
   const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);

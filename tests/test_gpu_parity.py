@@ -206,3 +206,40 @@ def test_sponza_class_pipelines_agree(api):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
         assert st2["rays"] == st["rays"], name
     scene.close()
+
+
+def _vs_oracle(api, tmp_path, s, p, tag):
+    from yart_amd import scenes
+    sp, pp, out = tmp_path / "e.yscn", tmp_path / "e.txt", tmp_path / "e.f32"
+    s.save(sp); scenes.write_params(pp, p)
+    subprocess.run([ORACLE_BIN, "render", str(sp), str(pp), str(out)], check=True, stdout=subprocess.DEVNULL)
+    scene = api.DeviceScene(s, device=0)
+    img, st = scene.render(p)
+    ref = np.fromfile(out, np.float32).reshape(img.shape)
+    same = float(np.mean(np.all(img.view(np.uint32) == ref.view(np.uint32), axis=-1)))
+    e = rmse(np.nan_to_num(img), np.nan_to_num(ref))
+    print(f"{tag}: rmse={e:.3e} identical_pixels={same:.4f} rays={st['rays']}")
+    scene.close()
+    return same, e
+
+
+@pytest.mark.skipif(not os.path.exists(ORACLE_BIN), reason="oracle restatement not built")
+def test_edge_cases_vs_oracle_live(api, tmp_path):
+    """Ragged and degenerate inputs against the CPU oracle: an image that is not a multiple of
+    the 64-pixel tile (partial tiles in both directions, one of them a single pixel wide), a
+    1x1 image, a scene without any light (only the background colour can arrive), a single
+    bounce, and a deep bounce budget on the all-materials scene."""
+    from yart_amd import scenes
+    cases = []
+    s, p = scenes.cornell(129, 65, 4, 4); cases.append(("cornell 129x65", s, p))
+    s, p = scenes.cornell(1, 1, 4, 4); cases.append(("cornell 1x1", s, p))
+    s, p = scenes.cornell(48, 48, 4, 4)
+    s.lights = []
+    for m in s.meshes:
+        m.face_light = np.full(len(m.faces), -1, np.int32)
+    p = dict(p, background=(0.25, 0.5, 0.75)); cases.append(("cornell without lights", s, p))
+    s, p = scenes.material_test(64, 48, 4, 1); cases.append(("material depth 1", s, p))
+    s, p = scenes.material_test(48, 32, 4, 24); cases.append(("material depth 24", s, p))
+    for tag, s, p in cases:
+        same, e = _vs_oracle(api, tmp_path, s, p, tag)
+        assert same > 0.99 or e < RMSE_TOL, tag

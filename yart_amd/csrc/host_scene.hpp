@@ -20,6 +20,7 @@
 namespace yart_hip {
 
 struct HostImage {
+  std::vector<ShadeTri> shadeTris;
   std::vector<BvhNode> bvhNodes;
   std::vector<LeafTri> leafTris;
   std::vector<u4> triVerts;
@@ -48,6 +49,7 @@ struct HostImage {
 
   SceneDev view() const {
     SceneDev s{};
+    s.shadeTris = shadeTris.data();
     s.bvhNodes = bvhNodes.data(); s.leafTris = leafTris.data(); s.triVerts = triVerts.data();
     s.triLight = triLight.data(); s.vPos = vPos.data(); s.vNormal = vNormal.data();
     s.vTangent = vTangent.data(); s.vUV = vUV.data(); s.meshes = meshes.data(); s.nodes = nodes.data();
@@ -209,6 +211,15 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
       u4 tv; tv.x = m.faces[4 * f]; tv.y = m.faces[4 * f + 1]; tv.z = m.faces[4 * f + 2]; tv.w = m.faces[4 * f + 3];
       im.triVerts.push_back(tv);
       im.triLight.push_back(m.face_light ? m.face_light[f] : -1);
+      ShadeTri st{};
+      const uint32_t vi[3] = {tv.x, tv.y, tv.z};
+      for (int k = 0; k < 3; k++) {
+        for (int c = 0; c < 3; c++) st.n[k][c] = m.normals[3 * size_t(vi[k]) + c];
+        for (int c = 0; c < 4; c++) st.t[k][c] = m.tangents[4 * size_t(vi[k]) + c];
+        for (int c = 0; c < 2; c++) st.uv[k][c] = m.uvs[2 * size_t(vi[k]) + c];
+      }
+      st.material = tv.w; st.light = m.face_light ? m.face_light[f] : -1;
+      im.shadeTris.push_back(st);
     }
     for (uint32_t v = 0; v < m.n_vertices; v++) {
       f4 p; p.x = m.positions[3 * v]; p.y = m.positions[3 * v + 1]; p.z = m.positions[3 * v + 2]; p.w = 0;

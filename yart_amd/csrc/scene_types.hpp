@@ -65,6 +65,18 @@ struct LeafTri {           // 48 bytes, leaf order
   float e2[3]; uint32_t material;
 };
 
+// Everything the shade stage needs about one triangle in one 128-byte line (vertex normals,
+// tangents, uvs, material, light) — instead of an index fetch followed by nine scattered vertex
+// attribute fetches (ten 64-byte sectors per shaded hit). Indexed like triVerts.
+struct ShadeTri {
+  float n[3][3];
+  float t[3][4];
+  float uv[3][2];
+  uint32_t material; int32_t light;
+  uint32_t pad[3];
+};
+static_assert(sizeof(ShadeTri) == 128, "ShadeTri is one cache line");
+
 struct MeshDev {
   uint32_t nodeOffset;     // into bvhNodes
   uint32_t leafOffset;     // into leafTris
@@ -121,6 +133,7 @@ struct LutDev {            // bsdf/luts.hpp:14-24 — float offsets into lutData
 
 // Everything a kernel needs, passed by value as a kernel argument (pointers into HBM).
 struct SceneDev {
+  const ShadeTri* shadeTris;
   const BvhNode* bvhNodes;
   const LeafTri* leafTris;
   const u4* triVerts;          // i0, i1, i2 (mesh-local vertex ids), material

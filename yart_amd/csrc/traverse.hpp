@@ -153,14 +153,12 @@ struct AlphaCtx {            // state the stochastic alpha test draws from
 // uv / normal interpolation of ray-integrator.cpp:198-213
 YART_HD void interpUVN(const SceneDev& sc, const MeshDev& mesh, uint32_t tri, float u, float v, f2& uv,
                        f3& n) {
-  const u4 tv = sc.triVerts[mesh.triOffset + tri];
+  const ShadeTri& st = sc.shadeTris[mesh.triOffset + tri];
   const float w = 1.0f - u - v;
-  const f2 t0 = sc.vUV[mesh.vertOffset + tv.x], t1 = sc.vUV[mesh.vertOffset + tv.y],
-           t2 = sc.vUV[mesh.vertOffset + tv.z];
+  const f2 t0 = mk2(st.uv[0][0], st.uv[0][1]), t1 = mk2(st.uv[1][0], st.uv[1][1]), t2 = mk2(st.uv[2][0], st.uv[2][1]);
   uv = (w * t0 + u * t1) + v * t2;
-  const f4 a = sc.vNormal[mesh.vertOffset + tv.x], b = sc.vNormal[mesh.vertOffset + tv.y],
-           c = sc.vNormal[mesh.vertOffset + tv.z];
-  n = (w * mk3(a.x, a.y, a.z) + u * mk3(b.x, b.y, b.z)) + v * mk3(c.x, c.y, c.z);
+  n = (w * mk3(st.n[0][0], st.n[0][1], st.n[0][2]) + u * mk3(st.n[1][0], st.n[1][1], st.n[1][2])) +
+      v * mk3(st.n[2][0], st.n[2][1], st.n[2][2]);
 }
 
 // testBVH (ray-integrator.cpp:84-160) + testTriangle (:163-229) for one mesh.
@@ -388,23 +386,21 @@ YART_HD Hit finalizeHit(const SceneDev& sc, const HitRec& r, f3 o, f3 d) {
   interpUVN(sc, mesh, r.tri, r.u, r.v, h.uv, n);
   h.p = oo + (r.t * od);                                   // ray(t), ray.hpp:27-29
   h.backSide = r.backSide != 0;
-  const u4 tv = sc.triVerts[mesh.triOffset + r.tri];
-  h.material = tv.w;
+  const ShadeTri& st = sc.shadeTris[mesh.triOffset + r.tri];
+  h.material = st.material;
   const MaterialDev& mt = sc.materials[h.material];
   // testMesh: tangents with barycentrics (w,u,v), normal map, tangent rebuilt from n x Y
   const float w = 1.0f - r.u - r.v;
-  const f4 t0 = sc.vTangent[mesh.vertOffset + tv.x], t1 = sc.vTangent[mesh.vertOffset + tv.y],
-           t2 = sc.vTangent[mesh.vertOffset + tv.z];
   f4 tg;
-  tg.x = (w * t0.x + r.u * t1.x) + r.v * t2.x;
-  tg.y = (w * t0.y + r.u * t1.y) + r.v * t2.y;
-  tg.z = (w * t0.z + r.u * t1.z) + r.v * t2.z;
-  tg.w = (w * t0.w + r.u * t1.w) + r.v * t2.w;
+  tg.x = (w * st.t[0][0] + r.u * st.t[1][0]) + r.v * st.t[2][0];
+  tg.y = (w * st.t[0][1] + r.u * st.t[1][1]) + r.v * st.t[2][1];
+  tg.z = (w * st.t[0][2] + r.u * st.t[1][2]) + r.v * st.t[2][2];
+  tg.w = (w * st.t[0][3] + r.u * st.t[1][3]) + r.v * st.t[2][3];
   n = bsdfNormal(sc, mt, n, tg, h.uv);
   f3 tang;
   if (absDot(n, mk3(0, 1, 0)) > 0.999f) tang = mk3(1, 0, 0);
   else tang = normalized(cross(n, mk3(0, 1, 0)));
-  h.lightIdx = sc.triLight[mesh.triOffset + r.tri];
+  h.lightIdx = st.light;
   // up the node chain: p as Point, n as Normal (renormalised per level), tg as Vector
   f3 p = h.p;
   for (int32_t i = int32_t(r.node); i >= 0; i = sc.nodes[i].parent) {

@@ -242,7 +242,7 @@ struct YartScene {
   SceneDev dev{};
   int numCUs = 256;
   // device copies of the scene image
-  DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
+  DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32;
   DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld;
@@ -263,6 +263,7 @@ namespace {
 
 void uploadScene(YartScene& s) {
   const HostImage& h = s.host;
+  s.shadeTris.upload(h.shadeTris);
   s.bvhNodes.upload(h.bvhNodes); s.leafTris.upload(h.leafTris); s.triVerts.upload(h.triVerts);
   s.triLight.upload(h.triLight); s.vPos.upload(h.vPos); s.vNormal.upload(h.vNormal);
   s.vTangent.upload(h.vTangent); s.vUV.upload(h.vUV); s.meshes.upload(h.meshes); s.nodes.upload(h.nodes);
@@ -271,6 +272,7 @@ void uploadScene(YartScene& s) {
   s.infiniteLights.upload(h.infiniteLights); s.areaLights.upload(h.areaLights);
   s.areaPowerCdf.upload(h.areaPowerCdf); s.lut.upload(h.lut);
   SceneDev d = h.view();       // counts and totals; pointers replaced below
+  d.shadeTris = s.shadeTris.p;
   d.bvhNodes = s.bvhNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;

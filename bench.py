@@ -127,7 +127,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     kernel_ms, launches = 0.0, 0
-    lean = (args.flags & 7) == 0       # default pipeline: the dominant kernel is k_wf_extend_fast
+    lean = (args.flags & 7) == 0       # default pipeline: the dominant kernel is the lean closest-hit kernel
     for _ in range(args.steps):
         step()
         if lean:
@@ -172,7 +172,7 @@ def main():
         # dominant kernel is the lean closest-hit kernel k_wf_extend_fast (its own counters, its own
         # HIP-event time, one launch per bounce per batch); otherwise all traversal launches together.
         if lean:
-            kname = "k_wf_extend_fast"
+            kname = "k_wf_extend_fast" if args.flags & 16 else "k_wf_extend_lean"
             trav_bytes = 32 * st2["lean_box_tests"] + 52 * st2["lean_tri_tests"] + 48 * st2["lean_traversals"]
             n_launch = max(1, last["launches_extend_lean"])
         else:
@@ -188,7 +188,7 @@ def main():
             # memory-side bytes per launch of this kernel from the committed PMC passes (tools/pmc_hbm.sh)
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))
-                k = next(v for n, v in prof["kernels"].items() if n.startswith("k_wf_extend_fast"))
+                k = next(v for n, v in prof["kernels"].items() if n.startswith(kname))
                 traffic = k["read_bytes_per_launch"] + k["write_bytes_per_launch"]
             except (OSError, StopIteration, KeyError, ValueError):
                 traffic = None

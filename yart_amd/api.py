@@ -33,7 +33,7 @@ FLAG_MEGAKERNEL = 1
 FLAG_WAVE_TRACE = 2
 FLAG_GENERAL_TRACE = 4
 FLAG_DIRECT_SAMPLER = 8
-FLAG_LEAN_REFILL = 16
+FLAG_NO_REFILL = 16
 
 
 class YartError(RuntimeError):

@@ -6,8 +6,8 @@
 // heavy-tailed traversal lengths (mean ≈ 37 inner steps, the slowest of 64 ≈ 170), so in the
 // one-ray-per-lane kernel 70-80 % of the lanes wait for the wave's slowest ray. Here
 //
-//   (A) lanes whose ray has finished take new queue entries as soon as at least kRefill lanes
-//       are out of the BVH (one ballot + one atomicAdd per refill),
+//   (A) lanes whose ray has finished take new queue entries once at least kLeanRefill lanes are out
+//       of the BVH (one ballot + one atomicAdd per refill), and get their scene-node candidate mask,
 //   (B) the scene-graph walk of all lanes that stand between two meshes runs to the point where
 //       each of them has entered a mesh or finished its ray,
 //   (C) "while-while": inner / pop steps until every lane inside a BVH stands at a leaf it must
@@ -21,9 +21,16 @@
 
 namespace yart_hip {
 
-constexpr uint32_t kLeanRefill = 16;      // refill when at least this many lanes are outside a BVH
+#ifndef YART_LEAN_REFILL
+#define YART_LEAN_REFILL 52
+#endif
+// measured on the C3 scene (reduced workload, extend / shadow ms): refill 16 -> 40.7 / 41.7, 32 -> 33.1 / 32.3,
+// 52 -> 31.4 / 30.6 (with inner-min 4); inner-min 1 -> 35.5 / 37.9, 8 -> 29.7 / 28.1, 12 -> 29.4 / 27.0;
+// the one-ray-per-lane kernels: 35.1 / 35.5. Few, well filled refill + walk rounds matter more than
+// keeping every lane busy; what is gained is the tail (the last lanes of a batch overlap the next one).
+constexpr uint32_t kLeanRefill = YART_LEAN_REFILL;      // refill when at least this many lanes are outside a BVH
 #ifndef YART_LEAN_INNER_MIN
-#define YART_LEAN_INNER_MIN 16
+#define YART_LEAN_INNER_MIN 12
 #endif
 constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;   // leave the inner loop when fewer lanes than this still step
 

@@ -403,7 +403,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const bool general = (p.flags & YART_FLAG_GENERAL_TRACE) != 0;
   const bool waveTrace = (p.flags & YART_FLAG_WAVE_TRACE) != 0;
   const bool ident = s.host.allIdentity;
-  const bool refill = (p.flags & YART_FLAG_LEAN_REFILL) != 0 && s.host.nodes.size() <= 64;   // per-ray node mask
+  const bool refill = (p.flags & YART_FLAG_NO_REFILL) == 0 && s.host.nodes.size() <= 64;   // per-ray node mask
   auto kExtendFast = refill ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_lean<TRAV_FAST>)
                             : (ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>);
   auto kShadowFast = refill ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_lean<TRAV_FAST>)

@@ -243,3 +243,27 @@ def test_edge_cases_vs_oracle_live(api, tmp_path):
     for tag, s, p in cases:
         same, e = _vs_oracle(api, tmp_path, s, p, tag)
         assert same > 0.99 or e < RMSE_TOL, tag
+
+
+@pytest.mark.skipif(not os.path.exists(ORACLE_BIN), reason="oracle restatement not built")
+@pytest.mark.parametrize("n_instances", [20, 58, 70])
+def test_instanced_scene_vs_oracle_live(api, tmp_path, n_instances):
+    """Scene-graph walk: nested transformed group / instance nodes. 58 instances = exactly 64
+    nodes (the capacity of the per-ray node candidate mask of trace_lean.hpp), 70 = 76 nodes (the
+    one-ray-per-lane lean kernels take over); every pipeline must reproduce the oracle."""
+    from yart_amd import scenes
+    s, p = scenes.instances(96, 96, 4, 4, n_instances=n_instances)
+    sp, pp, out = tmp_path / "i.yscn", tmp_path / "i.txt", tmp_path / "i.f32"
+    s.save(sp); scenes.write_params(pp, p)
+    subprocess.run([ORACLE_BIN, "render", str(sp), str(pp), str(out)], check=True, stdout=subprocess.DEVNULL)
+    scene = api.DeviceScene(s, device=0)
+    ref = None
+    for name, flags in PIPELINE_FLAGS.items():
+        img, st = scene.render(p, flags=flags)
+        if ref is None:
+            ref = np.fromfile(out, np.float32).reshape(img.shape)
+        same = float(np.mean(np.all(img.view(np.uint32) == ref.view(np.uint32), axis=-1)))
+        e = rmse(img, ref)
+        print(f"instances {len(s.nodes)} nodes / {name}: rmse={e:.3e} identical_pixels={same:.4f}")
+        assert e < RMSE_TOL and same > 0.99, name
+    scene.close()

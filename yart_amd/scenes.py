@@ -581,3 +581,36 @@ def write_params(path, p, threads=None, probe_pixels=None, **override):
         lines.append("probe_pixels " + " ".join(str(int(v)) for xy in probe_pixels for v in xy))
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
+
+
+def instances(width=96, height=96, spp=4, depth=4, n_instances=70, groups=4, seed=7):
+    """Cornell room + `n_instances` instanced unit boxes under `groups` transformed group nodes
+    (rotation + non-uniform scale + translation, nested two levels): exercises the scene-graph walk
+    (skip links, nested transform chains, world-space node culling, per-ray node candidate masks —
+    64 nodes is their capacity, so 1 + 1 + groups + n_instances is chosen around it by the tests)."""
+    s, p = cornell(width, height, spp, depth)
+    rng = np.random.RandomState(seed)
+    mats = [s.add_material(Material(base=tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0.2, 1.0)),
+                                    metallic=float(rng.rand() > 0.7))) for _ in range(4)]
+    b = MeshBuilder()
+    b.box((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), mats[0])
+    cube = s.add_mesh(b.build())
+
+    def trs(t, ry, sc):
+        cs, sn = math.cos(ry), math.sin(ry)
+        m = np.array([[cs * sc[0], 0, sn * sc[2], t[0]], [0, sc[1], 0, t[1]], [-sn * sc[0], 0, cs * sc[2], t[2]],
+                      [0, 0, 0, 1]], np.float64)
+        return m.astype(np.float32), np.linalg.inv(m).astype(np.float32)
+    group_nodes = []
+    for g in range(groups):
+        f, i = trs((rng.uniform(-1, 1), rng.uniform(0.5, 2.0), rng.uniform(-1, 1)), rng.uniform(-0.5, 0.5), (1.0, 1.0, 1.0))
+        group_nodes.append((g, f, i))
+    per = [n_instances // groups + (1 if g < n_instances % groups else 0) for g in range(groups)]
+    for g, f, i in group_nodes:                       # pre-order: group, then its instances
+        gi = s.add_node(-1, 0, f, i)
+        for _ in range(per[g]):
+            f2, i2 = trs((rng.uniform(-3.5, 3.5), rng.uniform(0.0, 6.0), rng.uniform(-3.5, 3.5)), rng.uniform(0, 6.28),
+                         tuple(rng.uniform(0.3, 0.9, 3)))
+            s.add_node(cube, gi, f2, i2)
+    s.create_area_lights()
+    return s, p

@@ -34,15 +34,18 @@ constexpr uint32_t kLeanRefill = YART_LEAN_REFILL;      // refill when at least 
 #endif
 constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;   // leave the inner loop when fewer lanes than this still step
 
-struct LeanRay { f3 o, d; float tMax; };
+struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general variant only (alpha tests)
 
 // Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)
-// Commit(slot, hit, didHit); Retry(pred, slot) appends to the retry queue (wave-wide call)
+// Commit(slot, hit, didHit, attenuation, samplerDim); Retry(pred, slot) appends to the retry queue
+// (wave-wide call). MODE without TRAV_FAST = the general walk (alpha tests inline, no hand-over).
 template <bool NEE, int MODE, class Fetch, class Commit, class Retry>
-__device__ __forceinline__ void traceLean(const SceneDev& sc, const TravStack& stk, const uint32_t* queue,
+__device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk, const uint32_t* queue,
                                           uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
                                           Retry retry, WfTally& tally) {
-  static_assert(MODE & TRAV_FAST, "lean tracer: no alpha code");
+  constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
+  Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
+  f3 attenuation = mk3(1.0f);
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long laneLt = (1ull << lane) - 1ull;
   const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
@@ -56,6 +59,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const TravStack& s
   const BvhNode* nodes = sc.bvhNodes;
   const LeafTri* leaves = sc.leafTris;
   bool meshHasAlpha = false;
+  uint32_t meshIdx = 0;
   // scene nodes this ray can reach at all: bit n survives if the padded world box of n and of all
   // its ancestors is hit within [0, tMax] (conservative, see traverseScene); requires nNodes <= 64
   unsigned long long cand = 0;
@@ -63,7 +67,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const TravStack& s
   AlphaCtx actx; actx.sampler = nullptr;     // only its counters are used (YART_COUNT)
 #endif
 
-#define LEAN_VISIT() (d < hit.t && (!NEE || !(didHit || meshDidHit) || (leftFirst & kLinkAlphaBit)))
+#define LEAN_VISIT() (d < hit.t && (!(NEE && kFast) || !(didHit || meshDidHit) || (leftFirst & kLinkAlphaBit)))
   for (;;) {
     // ------------------------------------------------------------------ (A) retry hand-over + refill
     retry(pendingRetry, slot);
@@ -94,6 +98,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const TravStack& s
           ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true;
           hit.t = r.tMax; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
           has = true; inMesh = false; nodeI = 0; didHit = false;
+          if (!kFast) { smp = r.smp; attenuation = mk3(1.0f); }
           YART_COUNT(nTrav, 1);
           cand = ~0ull;
         }
@@ -121,7 +126,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const TravStack& s
         WF_PHASE(tally, 3);                                     // walk steps
         const unsigned long long rest = nodeI < 64u ? (cand >> nodeI) : 0ull;
         if (rest == 0ull) {                                     // testNode of the root has returned
-          commit(slot, hit, didHit);
+          commit(slot, hit, didHit, attenuation, smp.dim);
           has = false;
         } else {
           nodeI += uint32_t(__builtin_ctzll(rest));             // next node the ray can reach
@@ -146,10 +151,10 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const TravStack& s
             bool entered = false;
             if (nd.mesh >= 0) {
               const MeshDev& mesh = sc.meshes[nd.mesh];
-              if (!(NEE && didHit && !mesh.hasAlpha)) {         // pruning of occluded shadow rays (traverse.hpp)
+              if (!(NEE && kFast && didHit && !mesh.hasAlpha)) { // pruning of occluded shadow rays (traverse.hpp)
                 nodes = sc.bvhNodes + mesh.nodeOffset;
                 leaves = sc.leafTris + mesh.leafOffset;
-                meshHasAlpha = mesh.hasAlpha != 0;
+                meshHasAlpha = mesh.hasAlpha != 0; meshIdx = uint32_t(nd.mesh);
                 const BvhNode root = nodes[0];
                 YART_COUNT(nBox, 1);
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
@@ -228,9 +233,24 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const TravStack& s
             if (v < 0.0f || u + v > 1.0f) break;
             const float t = dot(edge2, bEdge1) * invDet;
             if (t <= tMin || hit.t <= t) break;
-            if (tr.matFlags & ((NEE && !(didHit || meshDidHit)) ? (MAT_HAS_ALPHA | MAT_TRANSPARENT) : MAT_HAS_ALPHA)) {
-              pendingRetry = true;                              // the general kernel traces this ray again
-              break;
+            if (kFast) {
+              if (tr.matFlags & ((NEE && !(didHit || meshDidHit)) ? (MAT_HAS_ALPHA | MAT_TRANSPARENT) : MAT_HAS_ALPHA)) {
+                pendingRetry = true;                            // the general kernel traces this ray again
+                break;
+              }
+            } else if (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) {
+              // alpha cut-outs and NEE-transparent surfaces (ray-integrator.cpp:198-221)
+              f2 uv; f3 n;
+              interpUVN(sc, sc.meshes[meshIdx], tr.triIdx, u, v, uv, n);
+              const MaterialDev& mt = sc.materials[tr.material];
+              if (tr.matFlags & MAT_HAS_ALPHA) {
+                const float alpha = matAlpha(sc, mt, uv);
+                if (alpha < 1.0f && get1D(smp, scfg) > alpha) break;
+              }
+              if (NEE && (tr.matFlags & MAT_TRANSPARENT)) {
+                attenuation *= absDot(n, ray.d) * matBase(sc, mt, uv);
+                break;
+              }
             }
             hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeI;
             hit.backSide = det < 0 ? 1u : 0u;

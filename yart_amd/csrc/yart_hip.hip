@@ -414,10 +414,13 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend<false>), 8);
   const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow<false>), 8);
   const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shade), 8);
+  const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend_retry_lean), 8);
+  const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow_retry_lean), 8);
   const int gridTrE = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_extend), 8);
   const int gridTrS = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_shadow), 8);
   int gridMax = std::max(std::max(gridMega, gridTrE), std::max(gridTrS, std::max(gridExtend, gridShadow)));
   gridMax = std::max(gridMax, std::max(gridExtendFast, gridShadowFast));
+  gridMax = std::max(gridMax, std::max(gridRetryE, gridRetryS));
   s.spill.ensure(size_t(gridMax) * kBlock * kSpillDepthMax);
 
   // chunk the pixel list: per-sample radiance buffer <= ~1.5 GiB, wavefront state <= kWfMaxPaths
@@ -502,7 +505,8 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             tLean.begin(stream);
             hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
             tLean.end(stream);
-            hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+            if (refill) hipLaunchKernelGGL(k_wf_extend_retry_lean, dim3(gridRetryE), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
             hipLaunchKernelGGL(k_wf_reset_retry, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
           }
           HIP_CHECK(hipGetLastError());
@@ -518,7 +522,8 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           } else {
             hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
-            hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
+            if (refill) hipLaunchKernelGGL(k_wf_shadow_retry_lean, dim3(gridRetryS), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           }
           HIP_CHECK(hipGetLastError());
           tConnect.end(stream);

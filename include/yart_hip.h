@@ -117,8 +117,6 @@ typedef struct YartRenderParams {
 } YartRenderParams;
 
 #define YART_FLAG_MEGAKERNEL 1u     /* single-kernel integrator instead of the wavefront pipeline */
-#define YART_FLAG_WAVE_TRACE 2u     /* wave-level tracer kernels (trace_wave.hpp: dynamic refill + while-while)
-                                       for both ray kinds; A/B alternative to the default kernels */
 #define YART_FLAG_NO_REFILL 16u     /* one-ray-per-lane lean kernels instead of the ones with in-wave ray
                                        replacement (trace_lean.hpp; scenes of more than 64 nodes always use them) */
 #define YART_FLAG_DIRECT_SAMPLER 8u /* evaluate every ZSobol index digit per draw (no per-render sampler tables) */

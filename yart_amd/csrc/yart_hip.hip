@@ -30,7 +30,6 @@
 #include "integrator.hpp"
 #include "scene_file.hpp"
 #include "wavefront.hpp"
-#include "trace_wave.hpp"
 #include "trace_lean.hpp"
 
 using namespace yart_hip;
@@ -401,7 +400,6 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // lean traversal kernels when the scene allows them (every node transform chain the identity ->
   // identity-only variant); YART_FLAG_GENERAL_TRACE forces the general kernels for everything
   const bool general = (p.flags & YART_FLAG_GENERAL_TRACE) != 0;
-  const bool waveTrace = (p.flags & YART_FLAG_WAVE_TRACE) != 0;
   const bool ident = s.host.allIdentity;
   const bool refill = (p.flags & YART_FLAG_NO_REFILL) == 0 && s.host.nodes.size() <= 64;   // per-ray node mask
   auto kExtendFast = refill ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_lean<TRAV_FAST>)
@@ -416,9 +414,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shade), 8);
   const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend_retry_lean), 8);
   const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow_retry_lean), 8);
-  const int gridTrE = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_extend), 8);
-  const int gridTrS = persistentGrid(s, reinterpret_cast<const void*>(k_wf_trace_shadow), 8);
-  int gridMax = std::max(std::max(gridMega, gridTrE), std::max(gridTrS, std::max(gridExtend, gridShadow)));
+  int gridMax = std::max(gridMega, std::max(gridExtend, gridShadow));
   gridMax = std::max(gridMax, std::max(gridExtendFast, gridShadowFast));
   gridMax = std::max(gridMax, std::max(gridRetryE, gridRetryS));
   s.spill.ensure(size_t(gridMax) * kBlock * kSpillDepthMax);
@@ -497,9 +493,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         tShade.end(stream);
         for (uint32_t bounce = 0; bounce < rc.maxDepth; bounce++) {
           tExtend.begin(stream);
-          if (waveTrace) {
-            hipLaunchKernelGGL(k_wf_trace_extend, dim3(gridTrE), dim3(kTrBlock), 0, stream, a);
-          } else if (general) {
+          if (general) {
             hipLaunchKernelGGL(k_wf_extend<false>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
           } else {
             tLean.begin(stream);
@@ -516,9 +510,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           HIP_CHECK(hipGetLastError());
           tShade.end(stream);
           tConnect.begin(stream);
-          if (waveTrace) {
-            hipLaunchKernelGGL(k_wf_trace_shadow, dim3(gridTrS), dim3(kTrBlock), 0, stream, a);
-          } else if (general) {
+          if (general) {
             hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           } else {
             hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);

@@ -32,7 +32,7 @@ def api(built):
     return api
 
 
-PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+general_trace": 4,
+PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+shade_sort": 2, "wavefront+general_trace": 4,
                   "wavefront+direct_sampler": 8, "wavefront+no_refill": 16}
 
 
@@ -201,7 +201,7 @@ def test_sponza_class_pipelines_agree(api):
     scene = api.DeviceScene(s, device=0)
     a, st = scene.render(p)
     assert st["rays"] > 0 and np.isfinite(a).all()
-    for name in ("megakernel", "wavefront+general_trace", "wavefront+no_refill", "wavefront"):
+    for name in ("megakernel", "wavefront+shade_sort", "wavefront+general_trace", "wavefront+no_refill", "wavefront"):
         b, st2 = scene.render(p, flags=PIPELINE_FLAGS[name])
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
         assert st2["rays"] == st["rays"], name

@@ -30,6 +30,7 @@ LIB_PATH = os.path.join(_HERE, "libyart_hip.so")
 
 YART_OK, YART_E_INVALID, YART_E_NO_DEVICE, YART_E_HIP, YART_E_IO = 0, -1, -2, -3, -4
 FLAG_MEGAKERNEL = 1
+FLAG_SHADE_SORT = 2
 FLAG_GENERAL_TRACE = 4
 FLAG_DIRECT_SAMPLER = 8
 FLAG_NO_REFILL = 16

@@ -125,6 +125,7 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
   };
 
   // ---- materials (parametric.cpp:11-68) ---------------------------------------
+  require(d.n_materials < 2047, "more than 2046 materials are not supported");   // wavefront.hpp::wfHitWord
   for (uint32_t i = 0; i < d.n_materials; i++) {
     const YartMaterialDesc& m = d.materials[i];
     require(texOk(m.tex_base, 4, false) && texOk(m.tex_mr, 2, false) && texOk(m.tex_transmission, 1, false) &&
@@ -255,6 +256,7 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
       if (!ident) im.allIdentity = false;
     }
     require(nd.depth < kMaxNodeDepth, "scene graph deeper than 8 levels");
+    require(nn < (1u << 20), "more than 2^20 scene nodes are not supported");   // wavefront.hpp::wfHitWord
     if (nd.depth > im.maxNodeDepth) im.maxNodeDepth = nd.depth;
     if (n.mesh >= 0) {                                          // Node(Mesh*), scene.hpp:17-22
       const YartMeshDesc& m = d.meshes[n.mesh];

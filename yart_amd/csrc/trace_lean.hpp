@@ -253,7 +253,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
               }
             }
             hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeI;
-            hit.backSide = det < 0 ? 1u : 0u;
+            hit.backSide = (det < 0 ? 1u : 0u) | (tr.material << 1);
             accepted = true;
           } while (false);
           if (pendingRetry) break;

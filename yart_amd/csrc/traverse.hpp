@@ -119,7 +119,7 @@ struct HitRec {              // what the walk tracks of cpu/hit.hpp
   float u, v;                // barycentrics of p1, p2
   uint32_t tri;              // mesh-local triangle index (hit.idx)
   uint32_t node;             // scene node owning the hit
-  uint32_t backSide;
+  uint32_t backSide;         // bit 0: back side; bits 1..: material of the hit triangle (shade-queue class key)
 };
 
 // Instrumented build (-DYART_COUNT_TRAVERSAL, libyart_hip_count.so): exact numbers of
@@ -270,7 +270,7 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
           }
         }
         hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeIdx;
-        hit.backSide = det < 0 ? 1u : 0u;
+        hit.backSide = (det < 0 ? 1u : 0u) | (tr.material << 1);
         accepted = true;
       } while (false);
       didHit |= accepted;
@@ -385,7 +385,7 @@ YART_HD Hit finalizeHit(const SceneDev& sc, const HitRec& r, f3 o, f3 d) {
   f3 n;
   interpUVN(sc, mesh, r.tri, r.u, r.v, h.uv, n);
   h.p = oo + (r.t * od);                                   // ray(t), ray.hpp:27-29
-  h.backSide = r.backSide != 0;
+  h.backSide = (r.backSide & 1u) != 0;
   const ShadeTri& st = sc.shadeTris[mesh.triOffset + r.tri];
   h.material = st.material;
   const MaterialDev& mt = sc.materials[h.material];

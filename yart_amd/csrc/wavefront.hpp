@@ -21,7 +21,7 @@ namespace yart_hip {
 struct WfState {
   // ray0 = {o.xyz, d.x}  ray1 = {d.yz, lastPdf, accRoughness}
   // thr0 = {att.xyz, L.x} thr1 = {L.yz, flags(u32), dim(u32)}
-  // hit0 = {t, u, v, tri(u32)}  hit1 = {node|backSide<<31 (u32), morton.lo, morton.hi, sampler-table column (u32)}
+  // hit0 = {t, u, v, tri(u32)}  hit1 = {hit word (wfHitWord), morton.lo, morton.hi, sampler-table column (u32)}
   // sh0 = {to.xyz, cosTerm}  sh1 = {attPre.xyz, denom}  sh2 = {Lif.xyz, lightIsArea}
   f4 *ray0, *ray1, *thr0, *thr1, *hit0, *hit1, *sh0, *sh1, *sh2;
 };
@@ -64,6 +64,13 @@ struct WfTally {
 
 enum : uint32_t { WF_SPECULAR = 1u << 8, WF_REGULARIZED = 1u << 9, WF_MISS = 1u << 10, WF_DEPTH_MASK = 0xffu };
 
+// hit word of the path state: scene node (bits 0..19) | shade class = material index, or kWfClassMiss
+// (bits 20..30) | back side (bit 31). The class is what k_wf_shade buckets its waves by.
+constexpr uint32_t kWfNodeBits = 20, kWfClassBits = 11, kWfClassMiss = (1u << kWfClassBits) - 1u;
+YART_HD uint32_t wfHitWord(const HitRec& h, bool didHit) {
+  if (!didHit) return kWfClassMiss << kWfNodeBits;
+  return h.node | ((h.backSide >> 1) << kWfNodeBits) | ((h.backSide & 1u) << 31);
+}
 YART_HD float asF(uint32_t u) { return __builtin_bit_cast(float, u); }
 YART_HD uint32_t asU(float f) { return __builtin_bit_cast(uint32_t, f); }
 YART_HD f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
@@ -136,7 +143,7 @@ YART_HD void wfExtend(const SceneDev& sc, const RenderConst& rc, const TravStack
   bool hit = traverseScene<false>(sc, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), 0.001f, hr, dummy, stk, ac);
   WF_TALLY_TRAV(tally, ac);
   s.hit0[i] = mk4(hit ? hr.t : -1.0f, hr.u, hr.v, asF(hr.tri));
-  h1.x = asF(hr.node | (hr.backSide << 31));
+  h1.x = asF(wfHitWord(hr, hit));
   s.hit1[i] = h1;
   if (smp.dim != dim0) { t1.w = asF(smp.dim); s.thr1[i] = t1; }
 }
@@ -155,7 +162,7 @@ YART_HD bool wfExtendFast(const SceneDev& sc, const TravStack& stk, const WfStat
   WF_TALLY_TRAV(tally, ac);
   if (ac.deferred) return false;
   s.hit0[i] = mk4(hit ? hr.t : -1.0f, hr.u, hr.v, asF(hr.tri));
-  s.hit1[i].x = asF(hr.node | (hr.backSide << 31));
+  s.hit1[i].x = asF(wfHitWord(hr, hit));
   return true;
 }
 
@@ -213,7 +220,7 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
     return WF_TERMINATED;
   }
   HitRec hr;
-  hr.t = h0.x; hr.u = h0.y; hr.v = h0.z; hr.tri = asU(h0.w); hr.node = nodeBack & 0x7fffffffu; hr.backSide = nodeBack >> 31;
+  hr.t = h0.x; hr.u = h0.y; hr.v = h0.z; hr.tri = asU(h0.w); hr.node = nodeBack & ((1u << kWfNodeBits) - 1u); hr.backSide = nodeBack >> 31;
   Hit hit = finalizeHit(sc, hr, p.o, p.d);
   WF_TALLY_SHADE(tally);
   const MaterialDev& mt = sc.materials[hit.material];

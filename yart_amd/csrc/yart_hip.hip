@@ -411,7 +411,8 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);
   const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend<false>), 8);
   const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow<false>), 8);
-  const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shade), 8);
+  auto kShade = (p.flags & YART_FLAG_SHADE_SORT) ? k_wf_shade<true> : k_wf_shade<false>;
+  const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(kShade), 8);
   const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend_retry_lean), 8);
   const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow_retry_lean), 8);
   int gridMax = std::max(gridMega, std::max(gridExtend, gridShadow));
@@ -506,7 +507,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           HIP_CHECK(hipGetLastError());
           tExtend.end(stream);
           tShade.begin(stream);
-          hipLaunchKernelGGL(k_wf_shade, dim3(gridShade), dim3(kBlock), 0, stream, a);
+          hipLaunchKernelGGL(kShade, dim3(gridShade), dim3(kBlock), 0, stream, a);
           HIP_CHECK(hipGetLastError());
           tShade.end(stream);
           tConnect.begin(stream);

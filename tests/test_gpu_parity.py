@@ -267,3 +267,59 @@ def test_instanced_scene_vs_oracle_live(api, tmp_path, n_instances):
         print(f"instances {len(s.nodes)} nodes / {name}: rmse={e:.3e} identical_pixels={same:.4f}")
         assert e < RMSE_TOL and same > 0.99, name
     scene.close()
+
+
+@pytest.mark.skipif(not os.path.exists(ORACLE_BIN), reason="oracle restatement not built")
+def test_mclaren_class_waves_vs_oracle_live(api, tmp_path):
+    """BASELINE configs[4] scene family (thin + refractive dielectric, clearcoat, DoF at f/2.8) at a
+    size the CPU oracle finishes in a second, rendered as progressive waves (4 + 4 + 8 of 16 spp,
+    blended as tile-renderer.hpp:220-232 does) and sharded over two ranks: the sum of the two
+    half-frames must equal the oracle's frame."""
+    from yart_amd import scenes
+    s, p = scenes.mclaren_class(96, 54, 16, 8, detail=0.25, tex=64, sky=64)
+    p = dict(p, first_wave=4, max_wave=8)
+    sp, pp, out = tmp_path / "m.yscn", tmp_path / "m.txt", tmp_path / "m.f32"
+    s.save(sp); scenes.write_params(pp, p)
+    subprocess.run([ORACLE_BIN, "render", str(sp), str(pp), str(out)], check=True, stdout=subprocess.DEVNULL)
+    scene = api.DeviceScene(s, device=0)
+    img, st = scene.render(p)
+    ref = np.fromfile(out, np.float32).reshape(img.shape)
+    same = float(np.mean(np.all(img.view(np.uint32) == ref.view(np.uint32), axis=-1)))
+    e = rmse(img, ref)
+    print(f"mclaren_class 96x54x16 in {st['waves']} waves: rmse={e:.3e} identical_pixels={same:.4f}")
+    assert st["waves"] == 3
+    assert e < RMSE_TOL and same > 0.99
+    halves = [scene.render(p, rank=r, world_size=2)[0] for r in range(2)]
+    assert np.array_equal((halves[0] + halves[1]).view(np.uint32), img.view(np.uint32))
+    scene.close()
+
+
+def test_full_size_properties(api):
+    """BASELINE configs[2] at full size (1920x1080, 256 spp, 8 bounces; no CPU oracle finishes this in
+    test time): size-independent properties of the renderer.
+      * reproducibility: a second render is bit-identical (queues are filled with atomics, the result
+        must not depend on their order);
+      * partition: the frames of 8 tile-sharded ranks are disjoint and sum to the full frame, bit for bit;
+      * linearity in exposure: +1 EV scales every sample by exactly 2 before GMoN, and GMoN (sums, sort
+        by luma, Gini, trimmed mean) commutes with a power-of-two scale, so the frame doubles exactly;
+      * every pixel finite with alpha 1."""
+    from yart_amd import scenes
+    s, p = scenes.sponza_class(1920, 1080, 256, 8, tex=256, sky=512)
+    scene = api.DeviceScene(s, device=0)
+    full, st = scene.render(p)
+    assert np.isfinite(full).all() and np.all(full[..., 3] == 1.0)
+    assert st["samples"] == 1920 * 1080 * 256
+    again, _ = scene.render(p)
+    assert np.array_equal(full.view(np.uint32), again.view(np.uint32))
+    acc = np.zeros_like(full)
+    covered = np.zeros(full.shape[:2], np.int32)
+    for r in range(8):
+        part, _ = scene.render(p, rank=r, world_size=8)
+        covered += (part[..., 3] == 1.0)
+        acc += part
+    assert np.all(covered == 1)
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+    brighter, _ = scene.render(dict(p, exposure=p["exposure"] + 1.0))
+    assert np.array_equal((full[..., :3] * 2.0).view(np.uint32), brighter[..., :3].view(np.uint32))
+    print(f"full size: {1920 * 1080 * 256 / st['ms_device'] * 1e-3:.1f} Msamples/s")
+    scene.close()

@@ -180,6 +180,18 @@ int yart_hip_debug_counters(YartScene* scene, uint64_t* out32);
 int yart_hip_bvh_info(YartScene* scene, uint32_t mesh, uint32_t* n_nodes, uint32_t* n_tris);
 int yart_hip_bvh_copy(YartScene* scene, uint32_t mesh, uint32_t* nodes_out, uint32_t* indices_out);
 
+/* The step after the path: AgX tonemap of the RGBA32F frame as
+ * cpu/tile-renderer.hpp:234-237 applies it per tile (core/tonemapping.hpp:14-92; look 0 none, 1 golden,
+ * 2 punchy; alpha = 1), and the 8-bit encoding of output/ppm.cpp:7-21 (gamma 1/2.2, * 255.999, truncated;
+ * 3 bytes per pixel, row-major, no header). Device buffers; the calls return after completion on `stream`. */
+int yart_hip_tonemap_agx(const float* d_hdr_rgba, uint32_t width, uint32_t height, int look, float* d_ldr_rgba,
+                         void* stream);
+int yart_hip_encode_rgb8(const float* d_rgba, uint32_t width, uint32_t height, uint8_t* d_rgb8, void* stream);
+/* Host-buffer convenience: tonemap (look -1: none, as with a null tonemapper) + encode through the device;
+ * ldr_rgba / rgb8 may be NULL. */
+int yart_hip_tonemap_host(const float* hdr_rgba, uint32_t width, uint32_t height, int look, float* ldr_rgba,
+                          uint8_t* rgb8);
+
 const char* yart_hip_last_error(void);
 int yart_hip_abi_version(void);
 int yart_hip_device_count(void);

@@ -261,7 +261,77 @@ static int doRender(const Scene& sc, const params::Params& p, const std::string&
   return 0;
 }
 
+// ---- tonemap mode: AgX + PPM bytes (reference core/tonemapping.hpp:14-92, output/ppm.cpp:7-21) -------------
+// Scalar restatement with the reference's arithmetic order; double literals narrow to float where the
+// reference's `scalar * vec` does (vec.hpp:282-288), log2 / pow are libm's (std::log2, std::pow on float).
+namespace agx {
+struct V { float x, y, z; };
+static V mul(const float* m, V v) {             // float3x3 * float3, accumulate from 0 (mat.hpp:562-573)
+  return {((0.0f + m[0] * v.x) + m[1] * v.y) + m[2] * v.z, ((0.0f + m[3] * v.x) + m[4] * v.y) + m[5] * v.z,
+          ((0.0f + m[6] * v.x) + m[7] * v.y) + m[8] * v.z};
+}
+static float mn(float m, float n) { return m < n ? m : n; }      // math_base.hpp:83-92
+static float mx(float m, float n) { return m > n ? m : n; }
+static float contrast(float x) {
+  float x2 = x * x, x4 = x2 * x2;
+  return (((((((x4 * 15.5f) * x2) - ((x4 * 40.14f) * x)) + (x4 * 31.96f)) - ((x2 * 6.868f) * x)) + (x2 * 0.4298f)) +
+          (x * 0.1191f)) - 0.00232f;
+}
+static V tonemap(V hdr, int look) {
+  static const float A[9] = {float(0.842479062253094), float(0.0784335999999992), float(0.0792237451477643),
+                             float(0.0423282422610123), float(0.878468636469772), float(0.0791661274605434),
+                             float(0.0423756549057051), float(0.0784336), float(0.879142973793104)};
+  static const float I[9] = {float(1.19687900512017), float(-0.0980208811401368), float(-0.0990297440797205),
+                             float(-0.0528968517574562), float(1.15190312990417), float(-0.0989611768448433),
+                             float(-0.0529716355144438), float(-0.0980434501171241), float(1.15107367264116)};
+  const float minEv = -12.47393f, maxEv = 4.026069f;
+  float slope[3] = {1, 1, 1}, power[3] = {1, 1, 1}, sat = 1.0f;
+  if (look == 1) { slope[1] = 0.9f; slope[2] = 0.5f; power[0] = power[1] = power[2] = 0.8f; sat = 0.8f; }
+  if (look == 2) { power[0] = power[1] = power[2] = 1.35f; sat = 1.4f; }
+  V v = mul(A, hdr);
+  float c[3] = {v.x, v.y, v.z};
+  for (float& q : c) q = contrast((mn(maxEv, mx(minEv, std::log2(q))) - minEv) / (maxEv - minEv));
+  const float luma = ((0.0f + c[0] * 0.2126f) + c[1] * 0.7152f) + c[2] * 0.0722f;     // dot, vec.hpp
+  for (int k = 0; k < 3; k++) c[k] = luma + sat * (std::pow(c[k] * slope[k] + 0.0f, power[k]) - luma);
+  v = mul(I, V{c[0], c[1], c[2]});
+  float o[3] = {v.x, v.y, v.z};
+  for (float& q : o) q = std::pow(mn(1.0f, mx(0.0f, q)), 2.2f);
+  return {o[0], o[1], o[2]};
+}
+static uint8_t byteOf(float v) {
+  const float gamma = 1.0f / 2.2f;
+  float m = std::pow(v, gamma);
+  m = m < 0.0f ? 0.0f : (1.0f < m ? 1.0f : m);
+  if (!(m == m)) return 0;                        // x86 float -> uint8 of NaN
+  return uint8_t(m * 255.999f);
+}
+}  // namespace agx
+
+static int doTonemap(const char* in, unsigned w, unsigned h, const std::string& look, const char* outF32, const char* outPpm) {
+  std::vector<float> px(size_t(w) * h * 4);
+  FILE* f = std::fopen(in, "rb");
+  if (!f || std::fread(px.data(), 4, px.size(), f) != px.size()) throw std::runtime_error("tonemap: short input");
+  std::fclose(f);
+  const int lk = look == "golden" ? 1 : look == "punchy" ? 2 : look == "none" ? 0 : -1;
+  if (lk < 0 && look != "-") throw std::runtime_error("tonemap: unknown look");
+  std::vector<uint8_t> bytes(size_t(w) * h * 3);
+  for (size_t i = 0; i < size_t(w) * h; i++) {
+    if (lk >= 0) {
+      agx::V o = agx::tonemap({px[4 * i], px[4 * i + 1], px[4 * i + 2]}, lk);
+      px[4 * i] = o.x; px[4 * i + 1] = o.y; px[4 * i + 2] = o.z; px[4 * i + 3] = 1.0f;
+    }
+    for (int c = 0; c < 3; c++) bytes[3 * i + c] = agx::byteOf(px[4 * i + c]);
+  }
+  f = std::fopen(outF32, "wb"); std::fwrite(px.data(), 4, px.size(), f); std::fclose(f);
+  f = std::fopen(outPpm, "wb"); std::fprintf(f, "P6\n%u %u\n255\n", w, h); std::fwrite(bytes.data(), 1, bytes.size(), f); std::fclose(f);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 8 && std::string(argv[1]) == "tonemap") {
+    try { return doTonemap(argv[2], unsigned(std::atoi(argv[3])), unsigned(std::atoi(argv[4])), argv[5], argv[6], argv[7]); }
+    catch (const std::exception& e) { std::fprintf(stderr, "yart_oracle: %s\n", e.what()); return 2; }
+  }
   if (argc != 5) {
     std::fprintf(stderr, "usage: yart_oracle kat|render <scene.yscn> <params.txt> <out>\n");
     return 1;

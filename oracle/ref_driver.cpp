@@ -14,11 +14,15 @@
 //   yart_ref kat    <scene.yscn> <params.txt> <out.json>    known-answer vectors
 //   yart_ref luts   <out.bin>                               raw dump of the 8 LUT tables
 //   yart_ref bvh    <scene.yscn> <mesh> <out.bin>           node array + index array
+//   yart_ref tonemap <in.f32> <w> <h> <look|-> <out.f32> <out.ppm>   AgX (none|golden|punchy, "-": no
+//                   tonemapper) applied as tile-renderer.hpp:234-240 does, then output::writePPM
 #include <core/core.hpp>
 #include <cpu/tile-renderer.hpp>
 #include <cpu/mis-integrator.hpp>
 #include <bsdf/parametric.hpp>
 #include <bsdf/luts.hpp>
+#include <core/tonemapping.hpp>
+#include <output/ppm.hpp>
 
 #include <cstdio>
 #include <fstream>
@@ -489,6 +493,35 @@ static int doKat(const std::string& scenePath, const std::string& paramPath,
   return 0;
 }
 
+static int doTonemap(const char* in, unsigned w, unsigned h, const std::string& look, const char* outF32, const char* outPpm) {
+  std::ifstream f(in, std::ios::binary);
+  std::vector<float> hdr(size_t(w) * h * 4);
+  f.read(reinterpret_cast<char*>(hdr.data()), std::streamsize(hdr.size() * 4));
+  if (!f) throw std::runtime_error("tonemap: short input");
+  tonemap::AgX agx;
+  if (look == "golden") agx.look = tonemap::AgX::golden;
+  else if (look == "punchy") agx.look = tonemap::AgX::punchy;
+  else if (look != "none" && look != "-") throw std::runtime_error("tonemap: unknown look");
+  const tonemap::Tonemap* tm = look == "-" ? nullptr : &agx;
+  Buffer buf(w, h);
+  for (unsigned y = 0; y < h; y++)
+    for (unsigned x = 0; x < w; x++) {
+      const float* px = &hdr[(size_t(y) * w + x) * 4];
+      const float4 v(px[0], px[1], px[2], px[3]);
+      buf(x, y) = tm ? float4((*tm)(float3(v)), 1.0f) : v;      // tile-renderer.hpp:234-240
+    }
+  std::ofstream o(outF32, std::ios::binary);
+  for (unsigned y = 0; y < h; y++)
+    for (unsigned x = 0; x < w; x++) {
+      const float4& v = buf(x, y);
+      const float q[4] = {v[0], v[1], v[2], v[3]};
+      o.write(reinterpret_cast<const char*>(q), 16);
+    }
+  std::ofstream ppm(outPpm, std::ios::binary);
+  output::writePPM(ppm, buf);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   std::string mode = argc > 1 ? argv[1] : "";
   try {
@@ -496,6 +529,8 @@ int main(int argc, char** argv) {
     if (mode == "kat" && argc == 5) return doKat(argv[2], argv[3], argv[4]);
     if (mode == "luts" && argc == 3) return doLuts(argv[2]);
     if (mode == "bvh" && argc == 5) return doBvh(argv[2], size_t(std::atoi(argv[3])), argv[4]);
+    if (mode == "tonemap" && argc == 8)
+      return doTonemap(argv[2], unsigned(std::atoi(argv[3])), unsigned(std::atoi(argv[4])), argv[5], argv[6], argv[7]);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "yart_ref: %s\n", e.what());
     return 2;

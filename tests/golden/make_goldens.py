@@ -8,6 +8,10 @@ For each golden case it writes
     <case>.txt         camera / render parameters (input)
     <case>.kat.json    known-answer vectors evaluated by the reference (expected output)
     <case>.f32         linear-HDR RGBA32F framebuffer rendered by the reference (expected output)
+and, for the tonemap / output step (reference core/tonemapping.hpp + output/ppm.cpp, run by
+`yart_ref tonemap`), from the `material` frame (HDR values from 0 to the sun's brightness):
+    material.agx_<look>.f32   AgX-mapped RGBA32F frame for look in none / golden / punchy
+    material.agx_<look>.ppm   the P6 file output::writePPM makes of it ("raw" = no tonemapper)
 All files are data: inputs and the reference's outputs for them.
 """
 import os
@@ -54,6 +58,11 @@ def main():
                        stdout=subprocess.DEVNULL)
         print(name, {k: os.path.getsize(base + k) for k in (".yscn", ".kat.json", ".f32")})
     subprocess.run([REF, "luts", os.path.join(HERE, "ref_tables.bin")], check=True)
+    base = os.path.join(HERE, "material")
+    w, h = 96, 64
+    for look, tag in (("none", "none"), ("golden", "golden"), ("punchy", "punchy"), ("-", "raw")):
+        f32 = base + f".agx_{tag}.f32" if look != "-" else os.devnull
+        subprocess.run([REF, "tonemap", base + ".f32", str(w), str(h), look, f32, base + f".agx_{tag}.ppm"], check=True)
 
 
 if __name__ == "__main__":

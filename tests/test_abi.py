@@ -11,7 +11,7 @@ from tests.conftest import ROOT, GOLDEN
 
 def declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "yart_hip.h")).read()
-    return sorted(set(re.findall(r"\b(yart_hip_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(yart_hip_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_exports_match_header(built):

@@ -116,7 +116,8 @@ class Stats(C.Structure):
 EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error",
            "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
            "yart_hip_render", "yart_hip_render_device", "yart_hip_probe_samples",
-           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_debug_counters"]
+           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_debug_counters",
+           "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host"]
 
 LIB_COUNT_PATH = os.path.join(_HERE, "libyart_hip_count.so")   # instrumented twin (exact test counters)
 _libs = {}
@@ -144,6 +145,9 @@ def lib(instrumented: bool = False):
         L.yart_hip_probe_samples.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
                                              C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
         L.yart_hip_probe_hits.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.yart_hip_tonemap_agx.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.yart_hip_encode_rgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.yart_hip_tonemap_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.yart_hip_bvh_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.yart_hip_bvh_copy.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _libs[path] = L
@@ -357,3 +361,26 @@ class HipTileRenderer:
     def wait(self):
         if self._thread:
             self._thread.join()
+
+
+AGX_LOOKS = {"none": 0, "golden": 1, "punchy": 2}
+
+
+def tonemap(hdr: np.ndarray, look: Optional[str] = "none"):
+    """AgX tonemap (reference core/tonemapping.hpp; look None = no tonemapper) + the 8-bit encoding of
+    output/ppm.cpp of an (H, W, 4) float32 frame, on the device. Returns (ldr float32 (H,W,4), rgb8 (H,W,3))."""
+    hdr = np.ascontiguousarray(hdr, np.float32)
+    h, w = hdr.shape[:2]
+    ldr = np.empty_like(hdr)
+    rgb = np.empty((h, w, 3), np.uint8)
+    _check(lib().yart_hip_tonemap_host(hdr.ctypes.data_as(C.c_void_p), w, h, -1 if look is None else AGX_LOOKS[look],
+                                       ldr.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p)))
+    return ldr, rgb
+
+
+def write_ppm(path, rgb8: np.ndarray):
+    """P6 file as output/ppm.cpp:10 writes it."""
+    h, w = rgb8.shape[:2]
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h))
+        f.write(np.ascontiguousarray(rgb8, np.uint8).tobytes())

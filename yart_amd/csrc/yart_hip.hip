@@ -31,6 +31,7 @@
 #include "scene_file.hpp"
 #include "wavefront.hpp"
 #include "trace_lean.hpp"
+#include "tonemap.hpp"
 
 using namespace yart_hip;
 
@@ -172,6 +173,24 @@ __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
     o[1] = o[1] * a.wCurrent + v.y * a.wWave;
     o[2] = o[2] * a.wCurrent + v.z * a.wWave;
     o[3] = o[3] * a.wCurrent + 1.0f * a.wWave;
+  }
+}
+
+// AgX tonemap of an RGBA32F frame (alpha kept as 1, tile-renderer.hpp:234-237) and the 8-bit
+// encoding of output/ppm.cpp; one lane per pixel, 16 B in / 16 B (or 3 B) out: HBM-bound.
+__global__ void __launch_bounds__(kBlock) k_tonemap_agx(const f4* in, f4* out, uint32_t n, int look) {
+  const AgxLook lk = agxLook(look);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const f4 v = in[i];
+    const f3 c = agxTonemap(mk3(v.x, v.y, v.z), lk);
+    f4 o; o.x = c.x; o.y = c.y; o.z = c.z; o.w = 1.0f;
+    out[i] = o;
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_encode_rgb8(const f4* in, uint8_t* out, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const f4 v = in[i];
+    out[3 * size_t(i)] = ppmByte(v.x); out[3 * size_t(i) + 1] = ppmByte(v.y); out[3 * size_t(i) + 2] = ppmByte(v.z);
   }
 }
 
@@ -693,6 +712,57 @@ int yart_hip_probe_hits(YartScene* scene, uint32_t n, const float* rays, float* 
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(out, res.p, size_t(n) * 16 * 4, hipMemcpyDeviceToHost));
+  });
+}
+
+int yart_hip_tonemap_agx(const float* d_hdr_rgba, uint32_t width, uint32_t height, int look, float* d_ldr_rgba,
+                         void* stream) {
+  return guarded([&] {
+    require(d_hdr_rgba && d_ldr_rgba && width > 0 && height > 0 && look >= 0 && look <= 2, "tonemap: bad argument");
+    const uint32_t n = width * height;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_tonemap_agx, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                       reinterpret_cast<const f4*>(d_hdr_rgba), reinterpret_cast<f4*>(d_ldr_rgba), n, look);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st));
+  });
+}
+
+int yart_hip_encode_rgb8(const float* d_rgba, uint32_t width, uint32_t height, uint8_t* d_rgb8, void* stream) {
+  return guarded([&] {
+    require(d_rgba && d_rgb8 && width > 0 && height > 0, "encode: bad argument");
+    const uint32_t n = width * height;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_encode_rgb8, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                       reinterpret_cast<const f4*>(d_rgba), d_rgb8, n);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st));
+  });
+}
+
+int yart_hip_tonemap_host(const float* hdr_rgba, uint32_t width, uint32_t height, int look, float* ldr_rgba,
+                          uint8_t* rgb8) {
+  return guarded([&] {
+    require(hdr_rgba && width > 0 && height > 0 && look >= -1 && look <= 2, "tonemap: bad argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw HipError("no HIP device");
+    const size_t n = size_t(width) * height;
+    DevBuf<float> in, out; DevBuf<uint8_t> bytes;
+    in.ensure(n * 4); out.ensure(n * 4); bytes.ensure(n * 3);
+    HIP_CHECK(hipMemcpy(in.p, hdr_rgba, n * 16, hipMemcpyHostToDevice));
+    const float* src = in.p;
+    if (look >= 0) {                                           // look -1: no tonemapper (tile-renderer.hpp:238-240)
+      hipLaunchKernelGGL(k_tonemap_agx, dim3((uint32_t(n) + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr,
+                         reinterpret_cast<const f4*>(in.p), reinterpret_cast<f4*>(out.p), uint32_t(n), look);
+      HIP_CHECK(hipGetLastError());
+      src = out.p;
+    }
+    hipLaunchKernelGGL(k_encode_rgb8, dim3((uint32_t(n) + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr,
+                       reinterpret_cast<const f4*>(src), bytes.p, uint32_t(n));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    if (ldr_rgba) HIP_CHECK(hipMemcpy(ldr_rgba, src, n * 16, hipMemcpyDeviceToHost));
+    if (rgb8) HIP_CHECK(hipMemcpy(rgb8, bytes.p, n * 3, hipMemcpyDeviceToHost));
   });
 }
 

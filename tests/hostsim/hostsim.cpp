@@ -18,6 +18,7 @@
 #include "../../oracle/params.hpp"
 #include "../../yart_amd/csrc/estimator.hpp"
 #include "../../yart_amd/csrc/host_scene.hpp"
+#include "../../yart_amd/csrc/tonemap.hpp"
 #include "../../yart_amd/csrc/integrator.hpp"
 #include "../../yart_amd/csrc/scene_file.hpp"
 
@@ -377,12 +378,52 @@ static int doSelfTest() {
       }
     }
   }
+  // device log2f / powf (libm_pow.hpp) against this machine's libm: a dense random sweep (the exhaustive
+  // one — every float, ten exponents, 0 mismatches — takes minutes and was run once)
+  {
+    const float ys[] = {1.0f, 0.8f, 1.35f, 2.2f, 1.0f / 2.2f};
+    for (uint32_t rep = 0; rep < 1500000; rep++) {
+      uint32_t bits = rng.next();
+      if (rep % 3 == 0) bits = (bits & 0x007fffffu) | ((118u + rng.next() % 14u) << 23);   // around [2^-9, 2^5)
+      const float x = __builtin_bit_cast(float, bits);
+      const float a = libm_pow::log2f_(x), b = std::log2(x);
+      bool ok = (a != a && b != b) || std::memcmp(&a, &b, 4) == 0;
+      for (float y : ys) {
+        const float c = libm_pow::powf_(x, y), d = std::pow(x, y);
+        ok = ok && ((c != c && d != d) || std::memcmp(&c, &d, 4) == 0);
+      }
+      if (!ok) { std::fprintf(stderr, "selftest: log2f / powf emulation differs from libm at x=%a\n", x); return 3; }
+      checked++;
+    }
+  }
   std::printf("{\"selftest\": \"ok\", \"checked\": %llu}\n", (unsigned long long) checked);
+  return 0;
+}
+
+// tonemap: csrc/tonemap.hpp (the device functions, compiled for the host) over an RGBA32F file
+static int doTonemap(const char* in, unsigned w, unsigned h, const std::string& look, const char* outF32, const char* outPpm) {
+  std::vector<float> px(size_t(w) * h * 4);
+  FILE* f = std::fopen(in, "rb");
+  if (!f || std::fread(px.data(), 4, px.size(), f) != px.size()) { std::fprintf(stderr, "tonemap: short input\n"); return 2; }
+  std::fclose(f);
+  const int lk = look == "golden" ? 1 : look == "punchy" ? 2 : look == "none" ? 0 : -1;
+  std::vector<uint8_t> bytes(size_t(w) * h * 3);
+  for (size_t i = 0; i < size_t(w) * h; i++) {
+    if (lk >= 0) {
+      const f3 o = agxTonemap(mk3(px[4 * i], px[4 * i + 1], px[4 * i + 2]), agxLook(lk));
+      px[4 * i] = o.x; px[4 * i + 1] = o.y; px[4 * i + 2] = o.z; px[4 * i + 3] = 1.0f;
+    }
+    for (int c = 0; c < 3; c++) bytes[3 * i + c] = ppmByte(px[4 * i + c]);
+  }
+  f = std::fopen(outF32, "wb"); std::fwrite(px.data(), 4, px.size(), f); std::fclose(f);
+  f = std::fopen(outPpm, "wb"); std::fprintf(f, "P6\n%u %u\n255\n", w, h); std::fwrite(bytes.data(), 1, bytes.size(), f); std::fclose(f);
   return 0;
 }
 
 int main(int argc, char** argv) {
   if (argc == 2 && std::string(argv[1]) == "selftest") return doSelfTest();
+  if (argc == 8 && std::string(argv[1]) == "tonemap")
+    return doTonemap(argv[2], unsigned(std::atoi(argv[3])), unsigned(std::atoi(argv[4])), argv[5], argv[6], argv[7]);
   if (argc != 5) {
     std::fprintf(stderr, "usage: hostsim kat|render <scene.yscn> <params.txt> <out>\n");
     return 1;

@@ -1,10 +1,11 @@
 // tonemap.hpp — AgX tonemap and 8-bit output encoding (the step right after
 // the path). Restates reference core/tonemapping.hpp:14-92 (AgX::start / applyLook / end with the
 // looks none / golden / punchy) and the per-channel body of output/ppm.cpp:7-21, expression by
-// expression. log2 / pow are the platform's (glibc log2f / powf in the reference, ocml on the
-// device): results agree to a few ulp, not bit for bit — the parity tests state the tolerance.
+// expression. log2 / pow are glibc's log2f / powf in the reference; libm_pow.hpp evaluates the same
+// algorithms on the device, so the tonemapped frame and the bytes are the reference's bit for bit.
 #pragma once
 #include "ymath.hpp"
+#include "libm_pow.hpp"
 
 namespace yart_hip {
 
@@ -18,13 +19,10 @@ YART_HD AgxLook agxLook(int which) {           // tonemapping.hpp:21-34
   return l;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ float ylog2f(float x) { return __ocml_log2_f32(x); }
-__device__ __forceinline__ float ypowf(float x, float y) { return __ocml_pow_f32(x, y); }
-#else
-inline float ylog2f(float x) { return std::log2(x); }
-inline float ypowf(float x, float y) { return std::pow(x, y); }
-#endif
+// log2 / pow with glibc's values (libm_pow.hpp: its algorithms and tables, checked against libm over every
+// float for log2f and for the exponents used here), on the device and on the host alike
+YART_HD float ylog2f(float x) { return libm_pow::log2f_(x); }
+YART_HD float ypowf(float x, float y) { return libm_pow::powf_(x, y); }
 
 YART_HD f3 agxContrast(f3 x) {                 // tonemapping.hpp:43-54 (double literals narrow to float)
   const f3 x2 = x * x;

@@ -142,29 +142,15 @@ struct GmonArgs {
 constexpr int kGmonLanes = 16;
 static_assert(kGmonMax <= kGmonLanes, "one lane per bucket");
 constexpr int kGmonPixPerBlock = kBlock / kGmonLanes;
-// STAGED: the block's 16 pixels' samples (contiguous in L) are first copied to LDS with coalesced loads
-// (the per-bucket walk reads 12-byte items at a stride of 12 m bytes: measured 8.8x over-fetch from HBM);
-// used when they fit (spp <= kGmonStageSpp), else the buckets are summed straight from global memory.
-constexpr uint32_t kGmonStageSpp = 256;
-template <bool STAGED>
 __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
   __shared__ float sAcc[kGmonPixPerBlock][kGmonMax][4];
-  __shared__ float sL[STAGED ? kGmonPixPerBlock * kGmonStageSpp * 3 : 1];
   const uint32_t sub = threadIdx.x & (kGmonLanes - 1), lp = threadIdx.x / kGmonLanes;
-  const uint32_t pi0 = blockIdx.x * kGmonPixPerBlock;
-  const uint32_t pi = pi0 + lp;
+  const uint32_t pi = blockIdx.x * kGmonPixPerBlock + lp;
   const bool valid = pi < a.nPixels;
   const int m = gmonBuckets(int32_t(a.spp));
-  if (STAGED) {
-    const uint32_t nPix = a.nPixels - pi0 < uint32_t(kGmonPixPerBlock) ? a.nPixels - pi0 : uint32_t(kGmonPixPerBlock);
-    const uint32_t nFloats = nPix * a.spp * 3u;
-    const float* src = a.L + size_t(pi0) * a.spp * 3;
-    for (uint32_t i = threadIdx.x; i < nFloats; i += blockDim.x) sL[i] = src[i];
-    __syncthreads();
-  }
   if (valid && int(sub) < m) {
     f3 acc = mk3(0); uint32_t cnt = 0;
-    const float* p = STAGED ? sL + size_t(lp) * a.spp * 3 : a.L + size_t(pi) * a.spp * 3;
+    const float* p = a.L + size_t(pi) * a.spp * 3;
     for (uint32_t s = sub; s < a.spp; s += uint32_t(m)) {       // bucket k mod m, increasing k
       f3 v = mk3(p[s * 3], p[s * 3 + 1], p[s * 3 + 2]) * a.exposureScale;
       if (gmonAccepts(v)) { acc += v; cnt++; }
@@ -566,10 +552,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       g.L = s.L.p; g.pixels = s.pixels.p + c0; g.nPixels = n; g.spp = uint32_t(waveSamples); g.width = W;
       g.exposureScale = cam.exposureScale; g.wCurrent = wCurrent; g.wWave = wWave; g.hdr = dOut;
       tGmon.begin(stream);
-      if (g.spp <= kGmonStageSpp)
-        hipLaunchKernelGGL(k_gmon_blend<true>, dim3((n + kGmonPixPerBlock - 1) / kGmonPixPerBlock), dim3(kBlock), 0, stream, g);
-      else
-        hipLaunchKernelGGL(k_gmon_blend<false>, dim3((n + kGmonPixPerBlock - 1) / kGmonPixPerBlock), dim3(kBlock), 0, stream, g);
+      hipLaunchKernelGGL(k_gmon_blend, dim3((n + kGmonPixPerBlock - 1) / kGmonPixPerBlock), dim3(kBlock), 0, stream, g);
       HIP_CHECK(hipGetLastError());
       tGmon.end(stream);
       HIP_CHECK(hipStreamSynchronize(stream));

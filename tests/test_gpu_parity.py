@@ -167,7 +167,7 @@ ORACLE_BIN = os.path.join(os.path.dirname(REF_BIN), "..", "_build", "yart_oracle
 
 
 @pytest.mark.skipif(not os.path.exists(ORACLE_BIN), reason="oracle restatement not built")
-@pytest.mark.parametrize("spp", [1, 2, 8, 12, 90])
+@pytest.mark.parametrize("spp", [1, 2, 8, 12, 90, 300])
 def test_sample_counts_vs_oracle_live(api, tmp_path, spp):
     """Sampler corner cases against the CPU oracle: 1 spp (no sample digits), odd log2spp (the
     'pow2Samples' last digit), non-power-of-two counts, and 90 spp (log2Int rounds DOWN to 6, so

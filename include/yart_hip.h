@@ -113,7 +113,13 @@ typedef struct YartRenderParams {
   float background[3];
   uint32_t rank, world_size;
   uint32_t flags;            /* YART_FLAG_* */
-  uint32_t reserved[4];
+  /* Resumable accumulation (the reference keeps its blended m_hdrBuffer between waves, tile-renderer.hpp:93,
+   * 220-232): render only the waves that cover samples [start_sample, stop_sample) of the schedule that
+   * `samples / first_wave_samples / max_wave_samples` define; both must lie on wave boundaries of that
+   * schedule (stop_sample 0 = samples). With start_sample > 0 the output buffer must hold the frame
+   * accumulated so far and is blended into, exactly as an uninterrupted render would continue. */
+  uint32_t start_sample, stop_sample;
+  uint32_t reserved[2];
 } YartRenderParams;
 
 #define YART_FLAG_MEGAKERNEL 1u     /* single-kernel integrator instead of the wavefront pipeline */

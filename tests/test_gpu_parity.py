@@ -323,3 +323,23 @@ def test_full_size_properties(api):
     assert np.array_equal((full[..., :3] * 2.0).view(np.uint32), brighter[..., :3].view(np.uint32))
     print(f"full size: {1920 * 1080 * 256 / st['ms_device'] * 1e-3:.1f} Msamples/s")
     scene.close()
+
+
+def test_resumed_accumulation_equals_uninterrupted_render(api):
+    """YartRenderParams.start_sample / stop_sample: rendering the first wave, handing the frame back and
+    rendering the remaining waves must give the uninterrupted multi-wave render bit for bit (golden
+    `cornell_waves`: 8 + 8 spp), including through the host-buffer entry point; a start that is not a
+    wave boundary is rejected."""
+    base = os.path.join(GOLDEN, "cornell_waves")
+    p = load_params(base + ".txt")
+    scene = api.DeviceScene(base + ".yscn", device=0)
+    ref = np.fromfile(base + ".f32", np.float32).reshape(64, 64, 4)
+    first, st1 = scene.render(dict(p, stop_sample=8))
+    assert st1["waves"] == 1 and st1["samples"] == 64 * 64 * 8
+    assert not np.array_equal(first.view(np.uint32), ref.view(np.uint32))
+    rest, st2 = scene.render(dict(p, start_sample=8), accumulated=first)
+    assert st2["waves"] == 1 and st2["samples"] == 64 * 64 * 8
+    assert np.array_equal(rest.view(np.uint32), ref.view(np.uint32))
+    with pytest.raises(api.YartError):
+        scene.render(dict(p, start_sample=5), accumulated=first)
+    scene.close()

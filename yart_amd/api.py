@@ -96,7 +96,8 @@ class RenderParams(C.Structure):
     _fields_ = [("samples", C.c_uint32), ("first_wave_samples", C.c_uint32),
                 ("max_wave_samples", C.c_uint32), ("tile_size", C.c_uint32), ("max_depth", C.c_uint32),
                 ("background", C.c_float * 3), ("rank", C.c_uint32), ("world_size", C.c_uint32),
-                ("flags", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+                ("flags", C.c_uint32), ("start_sample", C.c_uint32), ("stop_sample", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
 
 
 class Stats(C.Structure):
@@ -182,6 +183,7 @@ def make_params(p: dict, rank=0, world_size=1, flags=0) -> RenderParams:
     r.tile_size = int(p.get("tile", 64)); r.max_depth = int(p.get("depth", 30))
     r.background = _f(p.get("background", (0, 0, 0)), 3)
     r.rank, r.world_size, r.flags = int(rank), int(world_size), int(flags)
+    r.start_sample, r.stop_sample = int(p.get("start_sample", 0)), int(p.get("stop_sample", 0))
     return r
 
 
@@ -244,10 +246,13 @@ class DeviceScene:
             pass
 
     # -- rendering ----------------------------------------------------------------
-    def render(self, p: dict, rank=0, world_size=1, flags=0):
-        """Blocking render to a host array (H, W, 4) float32 + stats dict."""
+    def render(self, p: dict, rank=0, world_size=1, flags=0, accumulated=None):
+        """Blocking render to a host array (H, W, 4) float32 + stats dict. `accumulated`: the frame of the
+        samples before p["start_sample"] when resuming (YartRenderParams.start_sample)."""
         cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
         out = np.empty((cam.height, cam.width, 4), np.float32)
+        if accumulated is not None:
+            out[...] = accumulated
         _check(self._L.yart_hip_render(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p),
                                      C.byref(st)))
         return out, st.asdict()

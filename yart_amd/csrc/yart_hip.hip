@@ -358,6 +358,8 @@ void validate(const YartCameraDesc* cam, const YartRenderParams* p) {
   require(p->tile_size > 0 && p->tile_size <= 4096, "tile_size out of range");
   require(p->world_size > 0 && p->rank < p->world_size, "rank / world_size");
   require(p->max_depth > 0, "max_depth must be > 0");
+  require(p->start_sample < p->samples && (p->stop_sample == 0 || (p->stop_sample > p->start_sample && p->stop_sample <= p->samples)),
+          "start_sample / stop_sample out of range");
 }
 
 RenderConst makeRenderConst(const YartRenderParams& p) {
@@ -412,7 +414,8 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   buildPixelList(s, W, H, p.tile_size, p.rank, p.world_size);
   const uint32_t nPix = uint32_t(s.pixelsHost.size());
 
-  HIP_CHECK(hipMemsetAsync(dOut, 0, size_t(W) * H * 4 * sizeof(float), stream));
+  const uint64_t startSample = p.start_sample, stopSample = p.stop_sample ? p.stop_sample : p.samples;
+  if (startSample == 0) HIP_CHECK(hipMemsetAsync(dOut, 0, size_t(W) * H * 4 * sizeof(float), stream));
   s.cursor.ensure(1); s.counters.ensure(kNumCounters);
   HIP_CHECK(hipMemsetAsync(s.counters.p, 0, kNumCounters * sizeof(unsigned long long), stream));
 
@@ -457,6 +460,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   Timer tAll;
   StageTimer tMega, tExtend, tShade, tConnect, tGmon, tLean;
   uint32_t waves = 0;
+  uint64_t renderedSamples = 0;
   HIP_CHECK(hipEventRecord(tAll.a, stream));
 
   // sampler tables (sampler.hpp::SamplerTables) for the wavefront pipeline; they require every
@@ -485,7 +489,12 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     const uint64_t takenBefore = p.samples - remaining, takenAfter = takenBefore + waveSamples;
     const float wCurrent = float(takenBefore) / float(takenAfter);
     const float wWave = float(waveSamples) / float(takenAfter);
-    for (uint32_t c0 = 0; c0 < nPix; c0 += chunk) {
+    // resumable accumulation: waves outside [start_sample, stop_sample) are not rendered by this call
+    const bool inRange = takenBefore >= startSample && takenBefore < stopSample;
+    if (!inRange && takenBefore < startSample && takenAfter > startSample) throw std::invalid_argument("start_sample is not a wave boundary");
+    if (inRange && takenAfter > stopSample) throw std::invalid_argument("stop_sample is not a wave boundary");
+    if (inRange) { waves++; renderedSamples += waveSamples; }
+    for (uint32_t c0 = 0; inRange && c0 < nPix; c0 += chunk) {
       const uint32_t n = std::min(chunk, nPix - c0);
       if (mega) {
         HIP_CHECK(hipMemsetAsync(s.cursor.p, 0, sizeof(uint32_t), stream));
@@ -561,7 +570,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     remaining -= waveSamples;
     uint64_t next = (currentWave > 0 || waveSamples > 1) ? std::min<uint64_t>(waveSamples * 2, p.max_wave_samples) : 1;
     waveSamples = std::min(next, remaining);
-    currentWave++; waves++;
+    currentWave++;
   }
   HIP_CHECK(hipEventRecord(tAll.b, stream));
   HIP_CHECK(hipEventSynchronize(tAll.b));
@@ -571,7 +580,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   for (int i = 0; i < kNumCounters; i++) s.lastCounters[i] = cnt[i];
   if (stats) {
     *stats = YartStats{};
-    stats->samples = uint64_t(nPix) * p.samples;
+    stats->samples = uint64_t(nPix) * renderedSamples;
     stats->rays = cnt[0];
     stats->traversals = cnt[1]; stats->box_tests = cnt[2]; stats->tri_tests = cnt[3]; stats->shaded_hits = cnt[4];
     stats->ms_device = msAll;
@@ -658,6 +667,7 @@ int yart_hip_render(YartScene* scene, const YartCameraDesc* cam, const YartRende
     HIP_CHECK(hipSetDevice(scene->device));
     const size_t n = size_t(cam->width) * cam->height * 4;
     scene->hdr.ensure(n);
+    if (params->start_sample > 0) HIP_CHECK(hipMemcpy(scene->hdr.p, out_rgba, n * sizeof(float), hipMemcpyHostToDevice));
     renderToDevice(*scene, *cam, *params, scene->hdr.p, nullptr, stats);
     HIP_CHECK(hipMemcpy(out_rgba, scene->hdr.p, n * sizeof(float), hipMemcpyDeviceToHost));
     if (stats)

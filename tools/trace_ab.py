@@ -8,7 +8,7 @@ from yart_amd import api, scenes
 if os.environ.get("YART_LIB"):          # experiment variant built by tools/build_variant.sh
     api.LIB_PATH = os.path.join(ROOT, "yart_amd", "_variants", os.environ["YART_LIB"] + ".so")
     print("variant", os.environ["YART_LIB"], flush=True)
-w, h, spp = 960, 540, 64
+w, h, spp = (int(x) for x in os.environ.get("SIZE", "960x540x64").split("x"))
 TEX, SKY = int(os.environ.get("TEX", 256)), int(os.environ.get("SKY", 256))
 scene, p = scenes.sponza_class(w, h, spp, 8, tex=TEX, sky=SKY)
 ds = api.DeviceScene(scene, device=0)

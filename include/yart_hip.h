@@ -124,7 +124,7 @@ typedef struct YartRenderParams {
 
 #define YART_FLAG_MEGAKERNEL 1u     /* single-kernel integrator instead of the wavefront pipeline */
 #define YART_FLAG_NO_REFILL 16u     /* one-ray-per-lane lean kernels instead of the ones with in-wave ray
-                                       replacement (trace_lean.hpp; scenes of more than 64 nodes always use them) */
+                                       replacement (trace_lean.hpp) */
 #define YART_FLAG_SHADE_SORT 2u     /* bucket each wave's 256 shade-queue entries by material before shading them
                                        (measured: +5 % shade time on the C3 scene, hence opt-in) */
 #define YART_FLAG_DIRECT_SAMPLER 8u /* evaluate every ZSobol index digit per draw (no per-render sampler tables) */

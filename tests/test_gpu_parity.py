@@ -246,11 +246,11 @@ def test_edge_cases_vs_oracle_live(api, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(ORACLE_BIN), reason="oracle restatement not built")
-@pytest.mark.parametrize("n_instances", [20, 58, 70])
+@pytest.mark.parametrize("n_instances", [20, 58, 70, 250])
 def test_instanced_scene_vs_oracle_live(api, tmp_path, n_instances):
     """Scene-graph walk: nested transformed group / instance nodes. 58 instances = exactly 64
-    nodes (the capacity of the per-ray node candidate mask of trace_lean.hpp), 70 = 76 nodes (the
-    one-ray-per-lane lean kernels take over); every pipeline must reproduce the oracle."""
+    nodes (one chunk of the per-ray node candidate mask of trace_lean.hpp), 70 = 76 nodes (two
+    chunks), 250 = 256 nodes (four); every pipeline must reproduce the oracle."""
     from yart_amd import scenes
     s, p = scenes.instances(96, 96, 4, 4, n_instances=n_instances)
     sp, pp, out = tmp_path / "i.yscn", tmp_path / "i.txt", tmp_path / "i.f32"

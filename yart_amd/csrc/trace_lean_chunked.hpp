@@ -1,0 +1,310 @@
+// trace_lean_chunked.hpp — trace_lean.hpp for scenes of more than 64 nodes (device only).
+//
+// Same algorithm; the per-ray scene-node candidate mask covers 64 nodes at a time (candBase), rebuilt when
+// the walk moves on to the next chunk, and a missed node's subtree is jumped over through its skip link.
+// Kept apart from trace_lean.hpp because the three extra words of lane state cost the 80-VGPR kernels
+// spills in their hot loops (measured: 28 -> 37 ms on the reduced C3 workload), which scenes that fit one
+// chunk should not pay.
+//
+// Per ray this is traverse.hpp's TRAV_FAST walk, operation for operation (same scene-node
+// order, same ordered BVH traversal, same leaf order, alpha / transparent candidates hand the
+// ray to the general kernel). What changes is how a 64-wide wave is kept busy: bounced rays have
+// heavy-tailed traversal lengths (mean ≈ 37 inner steps, the slowest of 64 ≈ 170), so in the
+// one-ray-per-lane kernel 70-80 % of the lanes wait for the wave's slowest ray. Here
+//
+//   (A) lanes whose ray has finished take new queue entries once at least kLeanRefill lanes are out
+//       of the BVH (one ballot + one atomicAdd per refill), and get their scene-node candidate mask,
+//   (B) the scene-graph walk of all lanes that stand between two meshes runs to the point where
+//       each of them has entered a mesh or finished its ray,
+//   (C) "while-while": inner / pop steps until every lane inside a BVH stands at a leaf it must
+//       test, then the leaves; repeated until fewer than 64 - kRefill lanes are inside a BVH.
+//
+// Lane state is small (object-space ray, hit, BVH cursor, stack index): the world ray of a lane
+// that re-enters the walk after a transformed node is re-read from the path state.
+#pragma once
+#if defined(__HIPCC__)
+#include "trace_lean.hpp"
+
+namespace yart_hip {
+
+// Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)
+// Commit(slot, hit, didHit, attenuation, samplerDim); Retry(pred, slot) appends to the retry queue
+// (wave-wide call). MODE without TRAV_FAST = the general walk (alpha tests inline, no hand-over).
+template <bool NEE, int MODE, class Fetch, class Commit, class Retry>
+__device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk, const uint32_t* queue,
+                                          uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
+                                          Retry retry, WfTally& tally) {
+  constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
+  Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
+  f3 attenuation = mk3(1.0f);
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long laneLt = (1ull << lane) - 1ull;
+  const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+  const float tMin = 0.001f;
+  bool has = false, inMesh = false, exhausted = false, firstFill = true, pendingRetry = false;
+  bool didHit = false, meshDidHit = false, rayIsWorld = false;
+  uint32_t slot = 0, nodeI = 0, leftFirst = 0, span = 0, stackIdx = 0;
+  float d = 0.0f;
+  RayO ray = makeRay(mk3(0.0f), mk3(1.0f));
+  HitRec hit; hit.t = 0; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
+  const BvhNode* nodes = sc.bvhNodes;
+  const LeafTri* leaves = sc.leafTris;
+  bool meshHasAlpha = false;
+  uint32_t meshIdx = 0;
+  // Scene nodes this ray can reach at all, 64 at a time: bit k of `cand` = node candBase + k, set if its
+  // padded world box and those of all its ancestors are hit within [0, hit.t] (conservative, see
+  // traverseScene). Built by one wave-uniform pass over the chunk's node boxes; a missed node's subtree
+  // is jumped over through its skip link (skipUntil).
+  unsigned long long cand = 0;
+  uint32_t candBase = 0, skipUntil = 0;
+  bool needMask = false;
+#if defined(YART_COUNT_TRAVERSAL)
+  AlphaCtx actx; actx.sampler = nullptr;     // only its counters are used (YART_COUNT)
+#endif
+
+#define LEANC_VISIT() (d < hit.t && (!(NEE && kFast) || !(didHit || meshDidHit) || (leftFirst & kLinkAlphaBit)))
+  for (;;) {
+    // ------------------------------------------------------------------ (A) retry hand-over + refill
+    retry(pendingRetry, slot);
+    pendingRetry = false;
+    if (has) WF_PHASE(tally, 5);                               // outer rounds / lanes holding a ray
+    const unsigned long long idle = __ballot(!has);
+    const uint32_t nIdle = uint32_t(__popcll(idle));
+    if (nIdle == 64u && exhausted) break;
+    if (!exhausted && nIdle >= kLeanRefill) {
+      uint32_t base;
+      if (firstFill) {                                          // by wave index, no atomic
+        firstFill = false;
+        base = waveId * 64u;
+        if (nWaves * 64u >= count) exhausted = true;
+      } else {
+        const int leader = __ffsll((long long) idle) - 1;
+        base = 0;
+        if (int(lane) == leader) base = atomicAdd(cursor, nIdle);
+        base = nWaves * 64u + __shfl(base, leader);
+        if (base + nIdle >= count) exhausted = true;           // wave-uniform
+      }
+      if (!has) {
+        const uint32_t k = base + uint32_t(__popcll(idle & laneLt));
+        if (k < count) {
+          WF_PHASE(tally, 6);                                   // refills / rays fetched
+          slot = queue[k];
+          const LeanRay r = fetch(slot);
+          ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true;
+          hit.t = r.tMax; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
+          has = true; inMesh = false; nodeI = 0; didHit = false;
+          if (!kFast) { smp = r.smp; attenuation = mk3(1.0f); }
+          YART_COUNT(nTrav, 1);
+          candBase = 0; skipUntil = 0;
+          needMask = true;
+        }
+      }
+    }
+
+    for (;;) {
+    // ------------------------------------------------------------------ (A') candidate masks
+    for (;;) {
+      const unsigned long long need = __ballot(has && needMask);
+      if (need == 0ull) break;
+      const uint32_t b = __shfl(candBase, __ffsll((long long) need) - 1);   // the chunk of this round
+      const bool mine = has && needMask && candBase == b;
+      uint32_t skipLocal = skipUntil;
+      if (mine && !rayIsWorld) { const LeanRay r = fetch(slot); ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true; }
+      unsigned long long m = 0ull;
+      const uint32_t end = b + 64u < sc.nNodes ? b + 64u : sc.nNodes;
+      for (uint32_t n = b; n < end; n++) {                      // wave-uniform addresses
+        const f4 wlo = sc.nodeWorld[2u * n], whi = sc.nodeWorld[2u * n + 1u];
+        if (mine && n >= skipLocal) {
+          WF_PHASE(tally, 4);                                   // candidate-mask box tests
+          const float wmin[3] = {wlo.x, wlo.y, wlo.z}, wmax[3] = {whi.x, whi.y, whi.z};
+          float dw;
+          YART_COUNT(nBox, 1);
+          if (testBox(ray, 0.0f, hit.t + (fabsf(hit.t) * 1e-4f + 1e-3f), wmin, wmax, dw)) m |= 1ull << (n - b);
+          else skipLocal = sc.nodes[n].skip;                      // jump over the subtree
+        }
+      }
+      if (mine) { cand = m; needMask = false; skipUntil = skipLocal; }
+    }
+
+    // ------------------------------------------------------------------ (B) scene-graph walk
+    {
+      while (has && !inMesh && !needMask) {                     // (lanes leave this loop one by one)
+        WF_PHASE(tally, 3);                                     // walk steps
+        if (nodeI >= sc.nNodes) {                               // testNode of the root has returned
+          commit(slot, hit, didHit, attenuation, smp.dim);
+          has = false;
+          break;
+        }
+        if (nodeI >= candBase + 64u) {               // next chunk of 64 nodes: its mask first
+          candBase = nodeI & ~63u; needMask = true;
+          if (skipUntil < nodeI) skipUntil = nodeI;
+          break;
+        }
+        const unsigned long long rest = cand >> (nodeI - candBase);
+        if (rest == 0ull) { nodeI = candBase + 64u; continue; }
+        {
+          nodeI += uint32_t(__builtin_ctzll(rest));             // next node the ray can reach
+          const NodeDev& nd = sc.nodes[nodeI];
+          bool skip = false;
+          if (!((MODE & TRAV_IDENTITY) || (nd.pad[0] & 1u))) {
+            // transformed node (its padded world box is known to be hit): the exact object-space ray
+            const LeanRay r = fetch(slot);                      // the exact world ray (ray.o/d carry +0.0f)
+            f3 oo, od;
+            objectRay(sc, nodeI, r.o, r.d, oo, od);
+            ray = makeRay(oo, od); rayIsWorld = false;
+          } else if (!rayIsWorld) {
+            const LeanRay r = fetch(slot); ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true;
+          }
+          float dd;
+          if (!skip) {
+            YART_COUNT(nBox, 1);
+            if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) skip = true;
+          }
+          if (skip) nodeI = nd.skip;                            // (bits of the subtree may remain set: skipped by index)
+          else {
+            bool entered = false;
+            if (nd.mesh >= 0) {
+              const MeshDev& mesh = sc.meshes[nd.mesh];
+              if (!(NEE && kFast && didHit && !mesh.hasAlpha)) { // pruning of occluded shadow rays (traverse.hpp)
+                nodes = sc.bvhNodes + mesh.nodeOffset;
+                leaves = sc.leafTris + mesh.leafOffset;
+                meshHasAlpha = mesh.hasAlpha != 0; meshIdx = uint32_t(nd.mesh);
+                const BvhNode root = nodes[0];
+                YART_COUNT(nBox, 1);
+                if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
+                  inMesh = true; entered = true;
+                  leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
+                }
+              }
+            }
+            if (!entered) nodeI++;
+          }
+        }
+      }
+    }
+
+    if (__ballot(has && needMask) == 0ull) break;               // a lane moved on to the next node chunk: mask, walk again
+    }
+
+    // ------------------------------------------------------------------ (C) BVH traversal, while-while
+    for (;;) {
+      // inner nodes and pops until every lane inside a BVH stands at a leaf it must test
+      {
+        while (inMesh && !(span > 0 && LEANC_VISIT())) {
+          WF_PHASE(tally, 0);                                   // inner / pop steps
+          bool pop = true;
+          if (LEANC_VISIT()) {
+            const BvhNode* pair = nodes + (leftFirst & kLinkIndexMask);
+            const BvhNode c1 = pair[0], c2 = pair[1];
+            YART_COUNT(nBox, 2);
+            float d1, d2;
+            bool hit1, hit2;
+            testBox2(ray, tMin, hit.t, c1, c2, hit1, hit2, d1, d2);
+            if (hit1 || hit2) {
+              const bool firstNear = hit1 && !(hit2 && d1 > d2);
+              if (hit1 && hit2)
+                stackPush(stk, stackIdx++, firstNear ? (c2.leftFirst | (c2.span << kSpanShift))
+                                                     : (c1.leftFirst | (c1.span << kSpanShift)),
+                          firstNear ? d2 : d1);
+              d = firstNear ? d1 : d2;
+              leftFirst = firstNear ? c1.leftFirst : c2.leftFirst;
+              span = firstNear ? c1.span : c2.span;
+              pop = false;
+            }
+          }
+          if (pop) {
+            if (stackIdx == 0) { inMesh = false; didHit |= meshDidHit; nodeI++; }     // testBVH returns
+            else {
+              uint32_t link;
+              stackPop(stk, --stackIdx, link, d);
+              leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
+            }
+          }
+          // the stragglers of the inner phase do not hold up the lanes waiting at their leaves:
+          // they step again after the leaf phase, together with the lanes that come back from it
+          if (uint32_t(__popcll(__ballot(true))) < kLeanInnerMin) break;
+        }
+      }
+      // leaves: triangles in index order
+      if (inMesh && span > 0 && LEANC_VISIT()) {
+        WF_PHASE(tally, 2);                                     // leaf visits
+        const uint32_t first = leftFirst & kLinkIndexMask;
+        for (uint32_t i = 0; i < span; i++) {
+          WF_PHASE(tally, 1);                                   // triangle tests
+          const LeafTri tr = leaves[first + i];
+          YART_COUNT(nTri, 1);
+          const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
+          const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
+          const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
+          bool accepted = false;
+          do {
+            const f3 rayEdge2 = cross(ray.d, edge2);
+            const float det = dot(edge1, rayEdge2);
+            if (double(fabsf(det)) < 1e-12) break;
+            const float invDet = 1.0f / det;
+            const f3 b = ray.o - p0;
+            const float u = dot(b, rayEdge2) * invDet;
+            if (u < 0.0f || u > 1.0f) break;
+            const f3 bEdge1 = cross(b, edge1);
+            const float v = dot(ray.d, bEdge1) * invDet;
+            if (v < 0.0f || u + v > 1.0f) break;
+            const float t = dot(edge2, bEdge1) * invDet;
+            if (t <= tMin || hit.t <= t) break;
+            if (kFast) {
+              if (tr.matFlags & ((NEE && !(didHit || meshDidHit)) ? (MAT_HAS_ALPHA | MAT_TRANSPARENT) : MAT_HAS_ALPHA)) {
+                pendingRetry = true;                            // the general kernel traces this ray again
+                break;
+              }
+            } else if (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) {
+              // alpha cut-outs and NEE-transparent surfaces (ray-integrator.cpp:198-221)
+              f2 uv; f3 n;
+              interpUVN(sc, sc.meshes[meshIdx], tr.triIdx, u, v, uv, n);
+              const MaterialDev& mt = sc.materials[tr.material];
+              if (tr.matFlags & MAT_HAS_ALPHA) {
+                const float alpha = matAlpha(sc, mt, uv);
+                if (alpha < 1.0f && get1D(smp, scfg) > alpha) break;
+              }
+              if (NEE && (tr.matFlags & MAT_TRANSPARENT)) {
+                attenuation *= absDot(n, ray.d) * matBase(sc, mt, uv);
+                break;
+              }
+            }
+            hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeI;
+            hit.backSide = (det < 0 ? 1u : 0u) | (tr.material << 1);
+            accepted = true;
+          } while (false);
+          if (pendingRetry) break;
+          meshDidHit |= accepted;
+          if (NEE && meshDidHit) break;
+        }
+        if (pendingRetry) { has = false; inMesh = false; }
+        else if (stackIdx == 0) { inMesh = false; didHit |= meshDidHit; nodeI++; }
+        else {
+          uint32_t link;
+          stackPop(stk, --stackIdx, link, d);
+          leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
+        }
+      }
+      if (uint32_t(__popcll(__ballot(inMesh))) < 64u - kLeanRefill + 1u) break;
+    }
+  }
+#undef LEANC_VISIT
+  (void)meshHasAlpha;
+#if defined(YART_COUNT_TRAVERSAL)
+  tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
+#else
+  (void)tally;
+#endif
+}
+
+// the kernels' entry: single-chunk form for scenes of up to 64 nodes, chunked form beyond
+template <bool NEE, int MODE, bool CHUNKED, class Fetch, class Commit, class Retry>
+__device__ __forceinline__ void traceLeanAny(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk,
+                                             const uint32_t* queue, uint32_t count, uint32_t* cursor, Fetch fetch,
+                                             Commit commit, Retry retry, WfTally& tally) {
+  if (CHUNKED) traceLeanChunked<NEE, MODE>(sc, scfg, stk, queue, count, cursor, fetch, commit, retry, tally);
+  else traceLean<NEE, MODE>(sc, scfg, stk, queue, count, cursor, fetch, commit, retry, tally);
+}
+
+}  // namespace yart_hip
+#endif  // __HIPCC__

@@ -31,6 +31,7 @@
 #include "scene_file.hpp"
 #include "wavefront.hpp"
 #include "trace_lean.hpp"
+#include "trace_lean_chunked.hpp"
 #include "tonemap.hpp"
 
 using namespace yart_hip;
@@ -423,11 +424,16 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // identity-only variant); YART_FLAG_GENERAL_TRACE forces the general kernels for everything
   const bool general = (p.flags & YART_FLAG_GENERAL_TRACE) != 0;
   const bool ident = s.host.allIdentity;
-  const bool refill = (p.flags & YART_FLAG_NO_REFILL) == 0 && s.host.nodes.size() <= 64;   // per-ray node mask
-  auto kExtendFast = refill ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_lean<TRAV_FAST>)
-                            : (ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>);
-  auto kShadowFast = refill ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_lean<TRAV_FAST>)
-                            : (ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>);
+  const bool refill = (p.flags & YART_FLAG_NO_REFILL) == 0;
+  const bool chunked = s.host.nodes.size() > 64;       // trace_lean.hpp: node candidate mask in chunks of 64
+  auto kExtendFast = !refill ? (ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>)
+                   : chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_extend_lean<TRAV_FAST, true>)
+                             : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_extend_lean<TRAV_FAST, false>);
+  auto kShadowFast = !refill ? (ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>)
+                   : chunked ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_shadow_lean<TRAV_FAST, true>)
+                             : (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_shadow_lean<TRAV_FAST, false>);
+  auto kRetryE = chunked ? k_wf_extend_retry_lean<true> : k_wf_extend_retry_lean<false>;
+  auto kRetryS = chunked ? k_wf_shadow_retry_lean<true> : k_wf_shadow_retry_lean<false>;
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
   const int gridExtendFast = persistentGrid(s, reinterpret_cast<const void*>(kExtendFast), 8);
   const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);
@@ -435,8 +441,8 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow<false>), 8);
   auto kShade = (p.flags & YART_FLAG_SHADE_SORT) ? k_wf_shade<true> : k_wf_shade<false>;
   const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(kShade), 8);
-  const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend_retry_lean), 8);
-  const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow_retry_lean), 8);
+  const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(kRetryE), 8);
+  const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(kRetryS), 8);
   int gridMax = std::max(gridMega, std::max(gridExtend, gridShadow));
   gridMax = std::max(gridMax, std::max(gridExtendFast, gridShadowFast));
   gridMax = std::max(gridMax, std::max(gridRetryE, gridRetryS));
@@ -528,7 +534,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             tLean.begin(stream);
             hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
             tLean.end(stream);
-            if (refill) hipLaunchKernelGGL(k_wf_extend_retry_lean, dim3(gridRetryE), dim3(kBlock), 0, stream, a);
+            if (refill) hipLaunchKernelGGL(kRetryE, dim3(gridRetryE), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
             hipLaunchKernelGGL(k_wf_reset_retry, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
           }
@@ -543,7 +549,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           } else {
             hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
-            if (refill) hipLaunchKernelGGL(k_wf_shadow_retry_lean, dim3(gridRetryS), dim3(kBlock), 0, stream, a);
+            if (refill) hipLaunchKernelGGL(kRetryS, dim3(gridRetryS), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           }
           HIP_CHECK(hipGetLastError());

@@ -75,6 +75,25 @@ YART_HD float asF(uint32_t u) { return __builtin_bit_cast(float, u); }
 YART_HD uint32_t asU(float f) { return __builtin_bit_cast(uint32_t, f); }
 YART_HD f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
+// Streaming access to the path state: every word is read / written once per kernel, so it is marked
+// non-temporal to keep it from displacing BVH nodes, leaf records and textures in L2.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(YART_NO_NT_STATE)
+typedef float wf_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 wfLd(const f4* p) {
+  const wf_v4 v = __builtin_nontemporal_load(reinterpret_cast<const wf_v4*>(p));
+  return mk4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void wfSt(f4* p, f4 v) {
+  wf_v4 q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+  __builtin_nontemporal_store(q, reinterpret_cast<wf_v4*>(p));
+}
+__device__ __forceinline__ void wfSt1(float* p, float v) { __builtin_nontemporal_store(v, p); }
+#else
+YART_HD f4 wfLd(const f4* p) { return *p; }
+YART_HD void wfSt(f4* p, f4 v) { *p = v; }
+YART_HD void wfSt1(float* p, float v) { *p = v; }
+#endif
+
 struct WfPath {             // register image of one path
   f3 o, d, att, L;
   float lastPdf, accRoughness;
@@ -82,7 +101,7 @@ struct WfPath {             // register image of one path
   Sampler smp;
 };
 YART_HD WfPath wfLoad(const WfState& s, uint32_t i) {
-  const f4 r0 = s.ray0[i], r1 = s.ray1[i], t0 = s.thr0[i], t1 = s.thr1[i], h1 = s.hit1[i];
+  const f4 r0 = wfLd(s.ray0 + i), r1 = wfLd(s.ray1 + i), t0 = wfLd(s.thr0 + i), t1 = wfLd(s.thr1 + i), h1 = wfLd(s.hit1 + i);
   WfPath p;
   p.o = mk3(r0.x, r0.y, r0.z); p.d = mk3(r0.w, r1.x, r1.y); p.lastPdf = r1.z; p.accRoughness = r1.w;
   p.att = mk3(t0.x, t0.y, t0.z); p.L = mk3(t0.w, t1.x, t1.y); p.flags = asU(t1.z); p.smp.dim = asU(t1.w);
@@ -90,12 +109,12 @@ YART_HD WfPath wfLoad(const WfState& s, uint32_t i) {
   return p;
 }
 YART_HD void wfStoreRay(const WfState& s, uint32_t i, const WfPath& p) {
-  s.ray0[i] = mk4(p.o.x, p.o.y, p.o.z, p.d.x);
-  s.ray1[i] = mk4(p.d.y, p.d.z, p.lastPdf, p.accRoughness);
+  wfSt(s.ray0 + i, mk4(p.o.x, p.o.y, p.o.z, p.d.x));
+  wfSt(s.ray1 + i, mk4(p.d.y, p.d.z, p.lastPdf, p.accRoughness));
 }
 YART_HD void wfStoreThr(const WfState& s, uint32_t i, const WfPath& p) {
-  s.thr0[i] = mk4(p.att.x, p.att.y, p.att.z, p.L.x);
-  s.thr1[i] = mk4(p.L.y, p.L.z, asF(p.flags), asF(p.smp.dim));
+  wfSt(s.thr0 + i, mk4(p.att.x, p.att.y, p.att.z, p.L.x));
+  wfSt(s.thr1 + i, mk4(p.L.y, p.L.z, asF(p.flags), asF(p.smp.dim)));
 }
 
 // Russian roulette and loop condition (mis-integrator.cpp:96-102 + the while at :21).
@@ -200,7 +219,7 @@ enum WfShadeResult { WF_TERMINATED = 0, WF_CONTINUE = 1, WF_SHADOW = 2 };
 YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const uint32_t* sobol, const WfState& s,
                               uint32_t i, WfPath& p, uint32_t& rays, WfTally& tally) {
   p = wfLoad(s, i);
-  const f4 h0 = s.hit0[i];
+  const f4 h0 = wfLd(s.hit0 + i);
   const uint32_t nodeBack = asU(s.hit1[i].x);
   const uint32_t depth = p.flags & WF_DEPTH_MASK;
   const bool specularBounce = (p.flags & WF_SPECULAR) != 0, regularized = (p.flags & WF_REGULARIZED) != 0;
@@ -264,9 +283,9 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
         float pdfLight = pl * ls.pdf / absDot(ls.n, ls.wi);
         if (l.type == LIGHT_AREA) pdfLight *= length2(hit.p - ls.p);
         const f3 Lif = ls.Li * f;
-        s.sh0[i] = mk4(ls.p.x, ls.p.y, ls.p.z, absDot(ls.wi, hit.n));
-        s.sh1[i] = mk4(p.att.x, p.att.y, p.att.z, pdfBSDF + pdfLight);
-        s.sh2[i] = mk4(Lif.x, Lif.y, Lif.z, 0.0f);
+        wfSt(s.sh0 + i, mk4(ls.p.x, ls.p.y, ls.p.z, absDot(ls.wi, hit.n)));
+        wfSt(s.sh1 + i, mk4(p.att.x, p.att.y, p.att.z, pdfBSDF + pdfLight));
+        wfSt(s.sh2 + i, mk4(Lif.x, Lif.y, Lif.z, 0.0f));
         shadow = true;
       }
     }

@@ -2,7 +2,7 @@
 # Rebuild every native target from the repo root (lib, instrumented twin, stats debug lib, hostsim).
 set -e
 cd "$(dirname "$0")/.."
-make -C yart_amd/csrc 2>&1 | grep -E "error|warning: " || true
+if ! make -C yart_amd/csrc > /tmp/yart_make.log 2>&1; then grep -E "error" /tmp/yart_make.log | head -20; echo "BUILD FAILED"; exit 1; fi
 if [ "$1" == "stats" ]; then
   (cd yart_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
      -DYART_TRACE_STATS=1 -shared -o ../libyart_hip_stats.so yart_hip.hip _gen/lut_data.cpp 2>&1 | grep -E "error" || true)

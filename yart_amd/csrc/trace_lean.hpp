@@ -41,14 +41,23 @@ struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general var
 // (wave-wide call). MODE without TRAV_FAST = the general walk (alpha tests inline, no hand-over).
 template <bool NEE, int MODE, class Fetch, class Commit, class Retry>
 __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk, const uint32_t* queue,
-                                          uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
+                                          uint32_t count, uint32_t* cursor, uint32_t nSegIn, Fetch fetch, Commit commit,
                                           Retry retry, WfTally& tally) {
   constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
   Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
   f3 attenuation = mk3(1.0f);
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long laneLt = (1ull << lane) - 1ull;
-  const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+  // XCD-aware dequeue: workgroups are dealt round-robin to the 8 XCDs (an affinity, used for speed only), so
+  // the queue is cut into nSeg contiguous segments with one cursor each and a wave starts in the segment of
+  // its XCD — neighbouring queue entries (camera rays: neighbouring pixels) then share one XCD's L2 — and
+  // moves on to the other segments when its own is drained. cursor points to nSeg words.
+  const uint32_t nSeg = (nSegIn > 1u && gridDim.x % nSegIn == 0u) ? nSegIn : 1u;
+  const uint32_t wavesPerBlock = blockDim.x >> 6;
+  const uint32_t localWave = (blockIdx.x / nSeg) * wavesPerBlock + (threadIdx.x >> 6);
+  const uint32_t wavesPerSeg = (gridDim.x / nSeg) * wavesPerBlock;
+  const uint32_t segLen = (((count + nSeg - 1u) / nSeg) + 63u) & ~63u;
+  uint32_t seg = blockIdx.x % nSeg, segsTried = 0;
   const float tMin = 0.001f;
   bool has = false, inMesh = false, exhausted = false, firstFill = true, pendingRetry = false;
   bool didHit = false, meshDidHit = false, rayIsWorld = false;
@@ -77,21 +86,26 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
     const uint32_t nIdle = uint32_t(__popcll(idle));
     if (nIdle == 64u && exhausted) break;
     if (!exhausted && nIdle >= kLeanRefill) {
-      uint32_t base;
+      uint32_t base = 0, segEnd = 0;
       if (firstFill) {                                          // by wave index, no atomic
         firstFill = false;
-        base = waveId * 64u;
-        if (nWaves * 64u >= count) exhausted = true;
+        base = seg * segLen + localWave * 64u;
+        segEnd = (seg + 1u) * segLen < count ? (seg + 1u) * segLen : count;
       } else {
         const int leader = __ffsll((long long) idle) - 1;
-        base = 0;
-        if (int(lane) == leader) base = atomicAdd(cursor, nIdle);
-        base = nWaves * 64u + __shfl(base, leader);
-        if (base + nIdle >= count) exhausted = true;           // wave-uniform
+        for (;;) {                                              // wave-uniform
+          uint32_t c = 0;
+          if (int(lane) == leader) c = atomicAdd(cursor + seg, nIdle);
+          base = seg * segLen + wavesPerSeg * 64u + __shfl(c, leader);
+          segEnd = (seg + 1u) * segLen < count ? (seg + 1u) * segLen : count;
+          if (base < segEnd) break;
+          seg = seg + 1u == nSeg ? 0u : seg + 1u;               // this segment is drained: the next one
+          if (++segsTried >= nSeg) { exhausted = true; break; }
+        }
       }
       if (!has) {
         const uint32_t k = base + uint32_t(__popcll(idle & laneLt));
-        if (k < count) {
+        if (k < segEnd) {
           WF_PHASE(tally, 6);                                   // refills / rays fetched
           slot = queue[k];
           const LeanRay r = fetch(slot);

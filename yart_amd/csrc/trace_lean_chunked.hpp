@@ -32,8 +32,8 @@ namespace yart_hip {
 // (wave-wide call). MODE without TRAV_FAST = the general walk (alpha tests inline, no hand-over).
 template <bool NEE, int MODE, class Fetch, class Commit, class Retry>
 __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk, const uint32_t* queue,
-                                          uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
-                                          Retry retry, WfTally& tally) {
+                                          uint32_t count, uint32_t* cursor, uint32_t /*nSeg: single cursor here*/, Fetch fetch,
+                                          Commit commit, Retry retry, WfTally& tally) {
   constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
   Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
   f3 attenuation = mk3(1.0f);
@@ -300,10 +300,10 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
 // the kernels' entry: single-chunk form for scenes of up to 64 nodes, chunked form beyond
 template <bool NEE, int MODE, bool CHUNKED, class Fetch, class Commit, class Retry>
 __device__ __forceinline__ void traceLeanAny(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk,
-                                             const uint32_t* queue, uint32_t count, uint32_t* cursor, Fetch fetch,
-                                             Commit commit, Retry retry, WfTally& tally) {
-  if (CHUNKED) traceLeanChunked<NEE, MODE>(sc, scfg, stk, queue, count, cursor, fetch, commit, retry, tally);
-  else traceLean<NEE, MODE>(sc, scfg, stk, queue, count, cursor, fetch, commit, retry, tally);
+                                             const uint32_t* queue, uint32_t count, uint32_t* cursor, uint32_t nSeg,
+                                             Fetch fetch, Commit commit, Retry retry, WfTally& tally) {
+  if (CHUNKED) traceLeanChunked<NEE, MODE>(sc, scfg, stk, queue, count, cursor, nSeg, fetch, commit, retry, tally);
+  else traceLean<NEE, MODE>(sc, scfg, stk, queue, count, cursor, nSeg, fetch, commit, retry, tally);
 }
 
 }  // namespace yart_hip

@@ -5,10 +5,10 @@
 //   extend    closest-hit traversal of every live path     (testNode, :20-54)
 //   shade     miss / emission / BSDF sample / NEE set-up / throughput update
 //             (mis-integrator.cpp:27-95, 111-124)
-//   connect   any-hit traversal of the shadow rays, NEE contribution (:125-133, 135-148)
-//   roulette  Russian roulette + next-bounce decision (:96-102) — runs at the end of
-//             `connect` for paths that cast a shadow ray (the shadow traversal may
-//             consume sampler dimensions first) and at the end of `shade` otherwise.
+//   shadow    any-hit traversal of the shadow rays -> {attenuation, occluded}     (:135-148)
+//   post      NEE contribution (:125-133) and, for the paths that cast a shadow ray, the Russian
+//             roulette + next-bounce decision (:96-102) — after the shadow traversal, which may
+//             consume sampler dimensions first; the other paths take it at the end of `shade`.
 //
 // Path state lives in HBM as float4-packed SoA arrays indexed by path slot, so that a
 // wave's 64 lanes read 1 KiB contiguous per field group. Every arithmetic expression is
@@ -24,12 +24,6 @@ struct WfState {
   // hit0 = {t, u, v, tri(u32)}  hit1 = {hit word (wfHitWord), morton.lo, morton.hi, sampler-table column (u32)}
   // sh0 = {to.xyz, cosTerm}  sh1 = {attPre.xyz, denom}  sh2 = {Lif.xyz, lightIsArea}
   f4 *ray0, *ray1, *thr0, *thr1, *hit0, *hit1, *sh0, *sh1, *sh2;
-};
-struct WfQueues {
-  uint32_t* active;     // path slots to extend + shade this bounce
-  uint32_t* next;       // survivors (filled by shade and connect)
-  uint32_t* shadow;     // path slots with a pending shadow ray
-  uint32_t* counters;   // [0] nActive [1] nNext [2] nShadow [3] cursorExtend [4] cursorShade [5] cursorConnect [6] cursorGen
 };
 // exact test counters of the instrumented build (libyart_hip_count.so); empty otherwise
 struct WfTally {

@@ -62,7 +62,7 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
   AlphaCtx actx; actx.sampler = nullptr;     // only its counters are used (YART_COUNT)
 #endif
 
-#define LEANC_VISIT() (d < hit.t && (!(NEE && kFast) || !(didHit || meshDidHit) || (leftFirst & kLinkAlphaBit)))
+#define LEAN_VISIT() (d < hit.t && (!(NEE && kFast) || !(didHit || meshDidHit) || (leftFirst & kLinkAlphaBit)))
   for (;;) {
     // ------------------------------------------------------------------ (A) retry hand-over + refill
     retry(pendingRetry, slot);
@@ -186,109 +186,9 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
     if (__ballot(has && needMask) == 0ull) break;               // a lane moved on to the next node chunk: mask, walk again
     }
 
-    // ------------------------------------------------------------------ (C) BVH traversal, while-while
-    for (;;) {
-      // inner nodes and pops until every lane inside a BVH stands at a leaf it must test
-      {
-        while (inMesh && !(span > 0 && LEANC_VISIT())) {
-          WF_PHASE(tally, 0);                                   // inner / pop steps
-          bool pop = true;
-          if (LEANC_VISIT()) {
-            const BvhNode* pair = nodes + (leftFirst & kLinkIndexMask);
-            const BvhNode c1 = pair[0], c2 = pair[1];
-            YART_COUNT(nBox, 2);
-            float d1, d2;
-            bool hit1, hit2;
-            testBox2(ray, tMin, hit.t, c1, c2, hit1, hit2, d1, d2);
-            if (hit1 || hit2) {
-              const bool firstNear = hit1 && !(hit2 && d1 > d2);
-              if (hit1 && hit2)
-                stackPush(stk, stackIdx++, firstNear ? (c2.leftFirst | (c2.span << kSpanShift))
-                                                     : (c1.leftFirst | (c1.span << kSpanShift)),
-                          firstNear ? d2 : d1);
-              d = firstNear ? d1 : d2;
-              leftFirst = firstNear ? c1.leftFirst : c2.leftFirst;
-              span = firstNear ? c1.span : c2.span;
-              pop = false;
-            }
-          }
-          if (pop) {
-            if (stackIdx == 0) { inMesh = false; didHit |= meshDidHit; nodeI++; }     // testBVH returns
-            else {
-              uint32_t link;
-              stackPop(stk, --stackIdx, link, d);
-              leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
-            }
-          }
-          // the stragglers of the inner phase do not hold up the lanes waiting at their leaves:
-          // they step again after the leaf phase, together with the lanes that come back from it
-          if (uint32_t(__popcll(__ballot(true))) < kLeanInnerMin) break;
-        }
-      }
-      // leaves: triangles in index order
-      if (inMesh && span > 0 && LEANC_VISIT()) {
-        WF_PHASE(tally, 2);                                     // leaf visits
-        const uint32_t first = leftFirst & kLinkIndexMask;
-        for (uint32_t i = 0; i < span; i++) {
-          WF_PHASE(tally, 1);                                   // triangle tests
-          const LeafTri tr = leaves[first + i];
-          YART_COUNT(nTri, 1);
-          const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
-          const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
-          const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
-          bool accepted = false;
-          do {
-            const f3 rayEdge2 = cross(ray.d, edge2);
-            const float det = dot(edge1, rayEdge2);
-            if (double(fabsf(det)) < 1e-12) break;
-            const float invDet = 1.0f / det;
-            const f3 b = ray.o - p0;
-            const float u = dot(b, rayEdge2) * invDet;
-            if (u < 0.0f || u > 1.0f) break;
-            const f3 bEdge1 = cross(b, edge1);
-            const float v = dot(ray.d, bEdge1) * invDet;
-            if (v < 0.0f || u + v > 1.0f) break;
-            const float t = dot(edge2, bEdge1) * invDet;
-            if (t <= tMin || hit.t <= t) break;
-            if (kFast) {
-              if (tr.matFlags & ((NEE && !(didHit || meshDidHit)) ? (MAT_HAS_ALPHA | MAT_TRANSPARENT) : MAT_HAS_ALPHA)) {
-                pendingRetry = true;                            // the general kernel traces this ray again
-                break;
-              }
-            } else if (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) {
-              // alpha cut-outs and NEE-transparent surfaces (ray-integrator.cpp:198-221)
-              f2 uv; f3 n;
-              interpUVN(sc, sc.meshes[meshIdx], tr.triIdx, u, v, uv, n);
-              const MaterialDev& mt = sc.materials[tr.material];
-              if (tr.matFlags & MAT_HAS_ALPHA) {
-                const float alpha = matAlpha(sc, mt, uv);
-                if (alpha < 1.0f && get1D(smp, scfg) > alpha) break;
-              }
-              if (NEE && (tr.matFlags & MAT_TRANSPARENT)) {
-                attenuation *= absDot(n, ray.d) * matBase(sc, mt, uv);
-                break;
-              }
-            }
-            hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeI;
-            hit.backSide = (det < 0 ? 1u : 0u) | (tr.material << 1);
-            accepted = true;
-          } while (false);
-          if (pendingRetry) break;
-          meshDidHit |= accepted;
-          if (NEE && meshDidHit) break;
-        }
-        if (pendingRetry) { has = false; inMesh = false; }
-        else if (stackIdx == 0) { inMesh = false; didHit |= meshDidHit; nodeI++; }
-        else {
-          uint32_t link;
-          stackPop(stk, --stackIdx, link, d);
-          leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
-        }
-      }
-      if (uint32_t(__popcll(__ballot(inMesh))) < 64u - kLeanRefill + 1u) break;
-    }
+#include "trace_lean_bvh.inc"
   }
-#undef LEANC_VISIT
+#undef LEAN_VISIT
   (void)meshHasAlpha;
 #if defined(YART_COUNT_TRAVERSAL)
   tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;

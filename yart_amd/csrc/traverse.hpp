@@ -57,33 +57,13 @@ YART_HD bool testBox(const RayO& r, float tIntMin, float tIntMax, const float* b
   return t1 >= t0;
 }
 
-// Both children of an inner node at once. Same operations per box as testBox; on the device
-// the six multiply/add pairs of the two boxes are issued as packed fp32 instructions
-// (v_pk_mul_f32 / v_pk_add_f32: two IEEE-rounded results per instruction, no contraction).
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef float v2f __attribute__((ext_vector_type(2)));
-#endif
+// Both children of an inner node at once (same operations per box as testBox). Issuing the six
+// multiply / add pairs of the two boxes as packed fp32 (v_pk_mul_f32 / v_pk_add_f32) was measured: it
+// saves 12 VALU per step but raises the register count past an occupancy step, and was slower.
 YART_HD void testBox2(const RayO& r, float tIntMin, float tIntMax, const BvhNode& c1, const BvhNode& c2,
                       bool& hit1, bool& hit2, float& d1, float& d2) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(YART_PACKED_BOX)
-  const v2f lo_x = {r.sx ? c1.bmax[0] : c1.bmin[0], r.sx ? c2.bmax[0] : c2.bmin[0]};
-  const v2f hi_x = {r.sx ? c1.bmin[0] : c1.bmax[0], r.sx ? c2.bmin[0] : c2.bmax[0]};
-  const v2f lo_y = {r.sy ? c1.bmax[1] : c1.bmin[1], r.sy ? c2.bmax[1] : c2.bmin[1]};
-  const v2f hi_y = {r.sy ? c1.bmin[1] : c1.bmax[1], r.sy ? c2.bmin[1] : c2.bmax[1]};
-  const v2f lo_z = {r.sz ? c1.bmax[2] : c1.bmin[2], r.sz ? c2.bmax[2] : c2.bmin[2]};
-  const v2f hi_z = {r.sz ? c1.bmin[2] : c1.bmax[2], r.sz ? c2.bmin[2] : c2.bmax[2]};
-  const v2f tmin0 = lo_x * r.idir.x + r.odir.x, tmin1 = lo_y * r.idir.y + r.odir.y, tmin2 = lo_z * r.idir.z + r.odir.z;
-  const v2f tmax0 = hi_x * r.idir.x + r.odir.x, tmax1 = hi_y * r.idir.y + r.odir.y, tmax2 = hi_z * r.idir.z + r.odir.z;
-  float a0 = tIntMin, a1 = tIntMax, b0 = tIntMin, b1 = tIntMax;
-  a0 = fmaxf(tmin0.x, a0); a0 = fmaxf(tmin1.x, a0); a0 = fmaxf(tmin2.x, a0);
-  a1 = fminf(tmax0.x, a1); a1 = fminf(tmax1.x, a1); a1 = fminf(tmax2.x, a1);
-  b0 = fmaxf(tmin0.y, b0); b0 = fmaxf(tmin1.y, b0); b0 = fmaxf(tmin2.y, b0);
-  b1 = fminf(tmax0.y, b1); b1 = fminf(tmax1.y, b1); b1 = fminf(tmax2.y, b1);
-  d1 = a0; d2 = b0; hit1 = a1 >= a0; hit2 = b1 >= b0;
-#else
   hit1 = testBox(r, tIntMin, tIntMax, c1.bmin, c1.bmax, d1);
   hit2 = testBox(r, tIntMin, tIntMax, c2.bmin, c2.bmax, d2);
-#endif
 }
 
 // Lane-private traversal stack: entry k of this lane is lds[k * ldsStride] for

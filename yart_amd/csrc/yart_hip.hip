@@ -448,11 +448,19 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   gridMax = std::max(gridMax, std::max(gridRetryE, gridRetryS));
   s.spill.ensure(size_t(gridMax) * kBlock * kSpillDepthMax);
 
-  // chunk the pixel list: per-sample radiance buffer <= ~1.5 GiB, wavefront state <= kWfMaxPaths
+  // Batch = as many pixels (x all samples of a wave) as half of the device memory that is free — or
+  // already held by this scene's scratch buffers — allows, up to kWfMaxPaths: 172 B per path (144 B of
+  // state, four queue words, 12 B of per-sample radiance). On a 288 GB MI355X the whole 1080p x 256 spp
+  // frame (531 M paths, 91 GB) is one batch: every launch is as large as it can be and the latency-bound
+  // tails of the late bounces are paid once per render instead of once per batch.
   const uint32_t maxWave = std::min(p.max_wave_samples, p.samples);
   const uint32_t waveCap = std::max(std::min(p.first_wave_samples, p.samples), maxWave);
-  uint64_t budgetFloats = (1536ull << 20) / 4;
-  uint64_t maxPaths = budgetFloats / 3;
+  size_t freeB = 0, totalB = 0;
+  HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+  uint64_t held = uint64_t(s.L.n) * 4 + (uint64_t(s.qA.n) + s.qB.n + s.qS.n + s.qR.n) * 4;
+  for (auto& b : s.wf) held += uint64_t(b.n) * 16;
+  const uint64_t perPath = mega ? 12 : 172;
+  uint64_t maxPaths = std::max<uint64_t>((uint64_t(freeB) + held) / 2 / perPath, 1u << 20);
   if (!mega) maxPaths = std::min<uint64_t>(maxPaths, kWfMaxPaths);
   maxPaths = std::min<uint64_t>(maxPaths, (1ull << 31) - 64);
   uint32_t chunk = uint32_t(std::min<uint64_t>(nPix ? nPix : 1, std::max<uint64_t>(maxPaths / waveCap, 1)));

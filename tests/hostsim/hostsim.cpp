@@ -396,6 +396,13 @@ static int doSelfTest() {
       checked++;
     }
   }
+  // byte / 255.0f of the texture fetch (bsdf.hpp byteToUnit) against the IEEE divide, all 256 numerators
+  for (uint32_t b = 0; b < 256; b++) {
+    volatile float x = float(b), c = 255.0f;
+    const float q = x / c, r = byteToUnit(b);
+    if (std::memcmp(&q, &r, 4) != 0) { std::fprintf(stderr, "selftest: byteToUnit(%u) differs from %u / 255.0f\n", b, b); return 3; }
+    checked++;
+  }
   std::printf("{\"selftest\": \"ok\", \"checked\": %llu}\n", (unsigned long long) checked);
   return 0;
 }

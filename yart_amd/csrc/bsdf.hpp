@@ -48,8 +48,17 @@ YART_HD uint32_t texelWord(const SceneDev& sc, const TexDev& t, uint32_t idx) {
   const uint64_t v = uint64_t(w[0]) | (uint64_t(w[1]) << 32);
   return uint32_t(v >> (8u * (b & 3u)));
 }
+// byte / 255.0f (texture.hpp:105-110) without the 11-instruction IEEE divide: for the 256 possible
+// numerators q = b * RN(1/255) followed by one exact-residual correction IS the correctly rounded
+// quotient (all 256 checked by hostsim selftest and tests/test_hostsim.py), 3 VALU instructions
+// per channel and tap instead of 11.
+YART_HD float byteToUnit(uint32_t b) {
+  const float x = float(b), r = 1.0f / 255.0f;
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
+}
 YART_HD float texelChannel(const TexDev& t, uint32_t word, uint32_t c) {
-  float v = float((word >> (8u * c)) & 0xffu) / 255.0f;
+  float v = byteToUnit((word >> (8u * c)) & 0xffu);
   if (t.type == TEX_SRGB && c < 3) v = v * v;                  // texture.hpp:111-113
   return v;
 }

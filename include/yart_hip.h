@@ -160,6 +160,27 @@ int yart_hip_scene_create(const YartSceneDesc* desc, int device, YartScene** out
 int yart_hip_scene_load(const char* path, int device, YartScene** out);
 void yart_hip_scene_destroy(YartScene* scene);
 
+/* glTF 2.0 / GLB import — what `gltf::load(path)` (src/gltf/gltf.cpp:319-358) followed
+ * by the frontend's environment set-up (src/main.cpp:78-86) gives the renderer: materials with the KHR
+ * transmission / ior / anisotropy / clearcoat / volume / emissive_strength extensions (gltf.cpp:62-176),
+ * gamma-2 re-encoded textures (core/texture.hpp:62-92), the primitives of each mesh merged (gltf.cpp:178-270),
+ * the T*R*S node tree and one AreaLight per emissive triangle with per-node light indices (gltf.cpp:272-317).
+ * Embedded PNG images are decoded; JPEG images and sparse accessors are refused (YART_E_IO, see
+ * yart_hip_last_error). opts may be NULL (asset only). env_hdr_path: octahedral-mapped Radiance .hdr wrapped
+ * in ImageInfiniteLight(env_radius, texture) (core/texture.cpp:5-20); uniform_env != 0 adds
+ * UniformInfiniteLight(env_radius, uniform_emission). env_radius <= 0 means 100 (main.cpp:82). */
+typedef struct YartImportOptions {
+  const char* env_hdr_path;
+  float env_radius;
+  uint32_t uniform_env;
+  float uniform_emission[3];
+  uint32_t reserved[4];
+} YartImportOptions;
+int yart_hip_scene_load_gltf(const char* path, const YartImportOptions* opts, int device, YartScene** out);
+/* Host only (no device needed): the imported scene written as a .yscn container — the same bytes
+ * yart_hip_scene_load reads, and what oracle/ takes to render the asset with the reference. */
+int yart_hip_gltf_to_yscn(const char* gltf_path, const YartImportOptions* opts, const char* yscn_path);
+
 /* Blocking render (Renderer::renderSync). out_rgba: caller-owned host buffer of
  * width*height*4 floats, linear HDR with exposure applied, alpha = 1 — the
  * reference's m_hdrBuffer (tile-renderer.hpp:93, tonemapper == nullptr). */

@@ -16,6 +16,15 @@
 //   yart_ref bvh    <scene.yscn> <mesh> <out.bin>           node array + index array
 //   yart_ref tonemap <in.f32> <w> <h> <look|-> <out.f32> <out.ppm>   AgX (none|golden|punchy, "-": no
 //                   tonemapper) applied as tile-renderer.hpp:234-240 does, then output::writePPM
+//   yart_ref texture <image file> <C> <type 0|1|2> <c0,c1,..> <out.bin>   loadTexture<C>(bytes, len, type,
+//                   channels) of core/texture.hpp:62-92 (stb_image decode + gamma-2 re-encode): u32 w, h, C + bytes
+//   yart_ref hdr    <file.hdr> <out.bin>                    loadTextureHDR (core/texture.cpp:5-20): u32 w, h + floats
+//   yart_ref xform  <in.txt> <out.bin>   per input line "tx ty tz qx qy qz qw sx sy sz parent": the node Transform
+//                   of gltf.cpp:284-291 (float4x4::translation * rotationFromQuat * float4x4::scaling, inverse by
+//                   Transform(float4x4)) and `node.transform * globalTransform` (:293) along the parent chain, with
+//                   the reference's own float4x4 / Transform classes. rotationFromQuat is a file-static function of
+//                   gltf.cpp (a TU that needs fastgltf), so its 10 lines are restated here on the reference's types.
+//                   Output per line: local fwd, local inv, global fwd, global inv (16 floats each).
 #include <core/core.hpp>
 #include <cpu/tile-renderer.hpp>
 #include <cpu/mis-integrator.hpp>
@@ -522,6 +531,84 @@ static int doTonemap(const char* in, unsigned w, unsigned h, const std::string& 
   return 0;
 }
 
+template <size_t C>
+static int textureDump(const std::vector<uint8_t>& file, TextureType type, const std::vector<uint32_t>& ch, const char* outPath) {
+  std::array<uint32_t, C> channels{};
+  for (size_t i = 0; i < C; i++) channels[i] = ch[i];
+  SDRTexture<C> t = loadTexture<C>(file.data(), int32_t(file.size()), type, channels);
+  std::ofstream o(outPath, std::ios::binary);
+  const uint32_t hdr[3] = {t.width(), t.height(), uint32_t(C)};
+  o.write(reinterpret_cast<const char*>(hdr), 12);
+  o.write(reinterpret_cast<const char*>(t.data.data()), std::streamsize(size_t(hdr[0]) * hdr[1] * C));
+  return 0;
+}
+
+static int doTexture(const char* inPath, int C, int type, const char* chans, const char* outPath) {
+  std::ifstream f(inPath, std::ios::binary);
+  if (!f) throw std::runtime_error(std::string("cannot open ") + inPath);
+  std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::vector<uint32_t> ch;
+  for (const char* p = chans; *p;) { ch.push_back(uint32_t(std::strtoul(p, const_cast<char**>(&p), 10))); if (*p == ',') p++; }
+  if (int(ch.size()) != C) throw std::runtime_error("channel list length != C");
+  const TextureType tt = type == 0 ? TextureType::LinearRGB : type == 1 ? TextureType::sRGB : TextureType::NonColor;
+  switch (C) {
+    case 1: return textureDump<1>(file, tt, ch, outPath);
+    case 2: return textureDump<2>(file, tt, ch, outPath);
+    case 3: return textureDump<3>(file, tt, ch, outPath);
+    case 4: return textureDump<4>(file, tt, ch, outPath);
+  }
+  throw std::runtime_error("C must be 1..4");
+}
+
+static int doHdr(const char* inPath, const char* outPath) {
+  HDRTexture t = loadTextureHDR(inPath);
+  std::ofstream o(outPath, std::ios::binary);
+  const uint32_t hdr[2] = {t.width(), t.height()};
+  o.write(reinterpret_cast<const char*>(hdr), 8);
+  o.write(reinterpret_cast<const char*>(t.data.data()), std::streamsize(size_t(hdr[0]) * hdr[1] * 3 * sizeof(float)));
+  return 0;
+}
+
+static float4x4 quatRotation(const float q[4]) {     // gltf.cpp:6-19, on the reference's float4x4
+  float qr = q[3], qi = q[0], qj = q[1], qk = q[2];
+  float4x4 half{
+    0.5f - (qj * qj + qk * qk), (qi * qj - qr * qk), (qi * qk + qr * qj), 0.0f,
+    (qi * qj + qr * qk), 0.5f - (qi * qi + qk * qk), (qj * qk - qr * qi), 0.0f,
+    (qi * qk - qr * qj), (qj * qk + qr * qi), 0.5f - (qi * qi + qj * qj), 0.0f,
+    0.0f, 0.0f, 0.0f, 0.5f
+  };
+  return half * 2.0f;
+}
+
+static int doXform(const char* inPath, const char* outPath) {
+  std::ifstream in(inPath);
+  if (!in) throw std::runtime_error(std::string("cannot open ") + inPath);
+  std::ofstream o(outPath, std::ios::binary);
+  std::vector<Transform> globals;
+  float t[3], q[4], s[3];
+  int parent;
+  // Transform keeps its matrices private: column j is read back as M * e_j (mat.hpp:561-572; exact up to the
+  // sign of zero entries, which "0 + m * 1" turns positive)
+  auto dump = [&](const Transform& x, bool inverse) {
+    float v[16];
+    for (size_t j = 0; j < 4; j++) {
+      float4 e(0.0f);
+      e[j] = 1.0f;
+      const float4 c = inverse ? x.inverse(e) : x(e);
+      for (size_t i = 0; i < 4; i++) v[i * 4 + j] = c[i];
+    }
+    o.write(reinterpret_cast<const char*>(v), sizeof(v));
+  };
+  while (in >> t[0] >> t[1] >> t[2] >> q[0] >> q[1] >> q[2] >> q[3] >> s[0] >> s[1] >> s[2] >> parent) {
+    const float4x4 m = float4x4::translation(float3(t[0], t[1], t[2])) * quatRotation(q) * float4x4::scaling(float3(s[0], s[1], s[2]));
+    const Transform local(m);
+    const Transform global = local * (parent >= 0 ? globals.at(size_t(parent)) : Transform());
+    globals.push_back(global);
+    dump(local, false); dump(local, true); dump(global, false); dump(global, true);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   std::string mode = argc > 1 ? argv[1] : "";
   try {
@@ -529,6 +616,9 @@ int main(int argc, char** argv) {
     if (mode == "kat" && argc == 5) return doKat(argv[2], argv[3], argv[4]);
     if (mode == "luts" && argc == 3) return doLuts(argv[2]);
     if (mode == "bvh" && argc == 5) return doBvh(argv[2], size_t(std::atoi(argv[3])), argv[4]);
+    if (mode == "texture" && argc == 7) return doTexture(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), argv[5], argv[6]);
+    if (mode == "hdr" && argc == 4) return doHdr(argv[2], argv[3]);
+    if (mode == "xform" && argc == 4) return doXform(argv[2], argv[3]);
     if (mode == "tonemap" && argc == 8)
       return doTonemap(argv[2], unsigned(std::atoi(argv[3])), unsigned(std::atoi(argv[4])), argv[5], argv[6], argv[7]);
   } catch (const std::exception& e) {

@@ -114,8 +114,37 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class ImportOptions(C.Structure):
+    """YartImportOptions (include/yart_hip.h): the environment the frontend adds after gltf::load."""
+    _fields_ = [("env_hdr_path", C.c_char_p), ("env_radius", C.c_float), ("uniform_env", C.c_uint32),
+                ("uniform_emission", C.c_float * 3), ("reserved", C.c_uint32 * 4)]
+
+
+def import_options(env_hdr=None, env_radius=100.0, uniform_env=None) -> ImportOptions:
+    o = ImportOptions()
+    o.env_hdr_path = os.fspath(env_hdr).encode() if env_hdr else None
+    o.env_radius = float(env_radius)
+    if uniform_env is not None:
+        o.uniform_env = 1
+        o.uniform_emission = _f(uniform_env, 3)
+    return o
+
+
+def is_gltf_path(path) -> bool:
+    return os.fspath(path).lower().endswith((".glb", ".gltf"))
+
+
+def gltf_to_yscn(gltf_path, yscn_path, env_hdr=None, env_radius=100.0, uniform_env=None):
+    """Import a glTF 2.0 / GLB asset the way the reference's loader does (src/gltf/gltf.cpp:319-358, plus the
+    environment of src/main.cpp:80-86) and write it as a ``.yscn`` container. Host only: needs no device."""
+    L = lib()
+    o = import_options(env_hdr, env_radius, uniform_env)
+    _check(L.yart_hip_gltf_to_yscn(os.fspath(gltf_path).encode(), C.byref(o), os.fspath(yscn_path).encode()), L)
+
+
 EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error",
            "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
+           "yart_hip_scene_load_gltf", "yart_hip_gltf_to_yscn",
            "yart_hip_render", "yart_hip_render_device", "yart_hip_probe_samples",
            "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_debug_counters",
            "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host"]
@@ -137,6 +166,8 @@ def lib(instrumented: bool = False):
         L.yart_hip_last_error.restype = C.c_char_p
         L.yart_hip_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.yart_hip_scene_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.yart_hip_scene_load_gltf.argtypes = [C.c_char_p, C.POINTER(ImportOptions), C.c_int, C.POINTER(C.c_void_p)]
+        L.yart_hip_gltf_to_yscn.argtypes = [C.c_char_p, C.POINTER(ImportOptions), C.c_char_p]
         L.yart_hip_scene_destroy.argtypes = [C.c_void_p]
         L.yart_hip_scene_destroy.restype = None
         L.yart_hip_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
@@ -190,11 +221,18 @@ def make_params(p: dict, rank=0, world_size=1, flags=0) -> RenderParams:
 class DeviceScene:
     """Owns a ``YartScene*`` (device-resident flattened scene + BVHs)."""
 
-    def __init__(self, scene, device: int = -1, instrumented: bool = False):
+    def __init__(self, scene, device: int = -1, instrumented: bool = False, env_hdr=None, env_radius=100.0,
+                 uniform_env=None):
+        """scene: a :class:`yscn.Scene`, the path of a ``.yscn`` container, or the path of a ``.glb`` / ``.gltf``
+        asset (then env_hdr / env_radius / uniform_env give the environment light, as main.cpp:80-86)."""
         self._h = C.c_void_p()
         self._keep = []
         self._L = lib(instrumented)
-        if isinstance(scene, (str, os.PathLike)):
+        if isinstance(scene, (str, os.PathLike)) and is_gltf_path(scene):
+            o = import_options(env_hdr, env_radius, uniform_env)
+            _check(self._L.yart_hip_scene_load_gltf(os.fspath(scene).encode(), C.byref(o), device, C.byref(self._h)),
+                   self._L)
+        elif isinstance(scene, (str, os.PathLike)):
             _check(self._L.yart_hip_scene_load(os.fspath(scene).encode(), device, C.byref(self._h)), self._L)
         else:
             desc = self._describe(scene)

@@ -22,6 +22,13 @@ struct LoadedScene {
   std::vector<YartNodeDesc> nodes;
   std::vector<YartLightDesc> lights;
   YartSceneDesc desc{};
+  // point desc at the vectors (after any of them changed)
+  void refreshDesc() {
+    desc.n_textures = uint32_t(textures.size()); desc.n_materials = uint32_t(materials.size());
+    desc.n_meshes = uint32_t(meshes.size()); desc.n_nodes = uint32_t(nodes.size()); desc.n_lights = uint32_t(lights.size());
+    desc.textures = textures.data(); desc.materials = materials.data(); desc.meshes = meshes.data();
+    desc.nodes = nodes.data(); desc.lights = lights.data();
+  }
 };
 
 inline std::unique_ptr<LoadedScene> loadSceneFile(const std::string& path) {
@@ -88,11 +95,37 @@ inline std::unique_ptr<LoadedScene> loadSceneFile(const std::string& path) {
     std::memcpy(&l, &file[pos], sizeof(l)); pos += sizeof(l);
     s->lights.push_back(l);
   }
-  s->desc.n_textures = nt; s->desc.n_materials = nm; s->desc.n_meshes = nme;
-  s->desc.n_nodes = nn; s->desc.n_lights = nl;
-  s->desc.textures = s->textures.data(); s->desc.materials = s->materials.data();
-  s->desc.meshes = s->meshes.data(); s->desc.nodes = s->nodes.data(); s->desc.lights = s->lights.data();
+  s->refreshDesc();
   return s;
+}
+
+// the same container, written (byte for byte what yart_amd/yscn.py Scene.tobytes() produces for the same scene)
+inline void saveSceneFile(const YartSceneDesc& d, const std::string& path) {
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) throw std::runtime_error("cannot create scene file " + path);
+  bool ok = true;
+  auto put = [&](const void* p, size_t n) { ok = ok && (n == 0 || std::fwrite(p, 1, n, f) == n); };
+  auto u32 = [&](uint32_t v) { put(&v, 4); };
+  auto arr = [&](const void* p, size_t n) { static const char zero[4] = {0, 0, 0, 0}; put(p, n); put(zero, (4 - n % 4) % 4); };
+  put("YSCN0001", 8);
+  u32(d.n_textures); u32(d.n_materials); u32(d.n_meshes); u32(d.n_nodes); u32(d.n_lights); u32(0); u32(0); u32(0);
+  for (uint32_t i = 0; i < d.n_textures; i++) {
+    const YartTextureDesc& t = d.textures[i];
+    u32(t.width); u32(t.height); u32(t.channels); u32(t.is_float); u32(t.type);
+    arr(t.data, size_t(t.width) * t.height * t.channels * (t.is_float ? 4 : 1));
+  }
+  for (uint32_t i = 0; i < d.n_materials; i++) put(&d.materials[i], sizeof(YartMaterialDesc));
+  for (uint32_t i = 0; i < d.n_meshes; i++) {
+    const YartMeshDesc& m = d.meshes[i];
+    u32(m.n_vertices); u32(m.n_faces);
+    arr(m.positions, size_t(m.n_vertices) * 12); arr(m.normals, size_t(m.n_vertices) * 12);
+    arr(m.tangents, size_t(m.n_vertices) * 16); arr(m.uvs, size_t(m.n_vertices) * 8);
+    arr(m.faces, size_t(m.n_faces) * 16); arr(m.face_light, size_t(m.n_faces) * 4);
+  }
+  for (uint32_t i = 0; i < d.n_nodes; i++) put(&d.nodes[i], sizeof(YartNodeDesc));
+  for (uint32_t i = 0; i < d.n_lights; i++) put(&d.lights[i], sizeof(YartLightDesc));
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok) throw std::runtime_error("write error on " + path);
 }
 
 }  // namespace yart_hip

@@ -29,6 +29,7 @@
 #include "host_scene.hpp"
 #include "integrator.hpp"
 #include "scene_file.hpp"
+#include "gltf_reader.hpp"
 #include "wavefront.hpp"
 #include "trace_lean.hpp"
 #include "trace_lean_chunked.hpp"
@@ -652,6 +653,34 @@ int yart_hip_scene_load(const char* path, int device, YartScene** out) {
     require(path && out, "path / out pointer is null");
     auto loaded = loadSceneFile(path);
     *out = createScene(loaded->desc, device);
+  });
+}
+
+namespace {
+std::unique_ptr<LoadedScene> importGltf(const char* path, const YartImportOptions* opts) {
+  auto loaded = gltf::loadGltf(path);
+  if (opts) {
+    const float radius = opts->env_radius > 0.0f ? opts->env_radius : 100.0f;      // frontend main.cpp:82
+    if (opts->env_hdr_path && opts->env_hdr_path[0]) gltf::addImageEnvironment(*loaded, opts->env_hdr_path, radius);
+    if (opts->uniform_env) gltf::addUniformEnvironment(*loaded, opts->uniform_emission, radius);
+  }
+  return loaded;
+}
+}  // namespace
+
+int yart_hip_scene_load_gltf(const char* path, const YartImportOptions* opts, int device, YartScene** out) {
+  return guarded([&] {
+    require(path && out, "path / out pointer is null");
+    auto loaded = importGltf(path, opts);
+    *out = createScene(loaded->desc, device);
+  });
+}
+
+int yart_hip_gltf_to_yscn(const char* gltf_path, const YartImportOptions* opts, const char* yscn_path) {
+  return guarded([&] {
+    require(gltf_path && yscn_path, "path pointer is null");
+    auto loaded = importGltf(gltf_path, opts);
+    saveSceneFile(loaded->desc, yscn_path);
   });
 }
 

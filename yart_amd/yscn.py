@@ -246,6 +246,52 @@ class Scene:
         with open(path, "wb") as f:
             f.write(self.tobytes())
 
+    @classmethod
+    def frombytes(cls, buf: bytes) -> "Scene":
+        """Inverse of :meth:`tobytes` (e.g. to inspect or edit what the glTF importer produced)."""
+        if buf[:8] != MAGIC:
+            raise ValueError("not a .yscn container")
+        pos = 8
+        nt, nm, nme, nn, nl, _, _, _ = struct.unpack_from("<8I", buf, pos); pos += 32
+
+        def arr(dtype, count, shape):
+            nonlocal pos
+            a = np.frombuffer(buf, dtype=dtype, count=count, offset=pos).reshape(shape).copy()
+            nbytes = a.nbytes
+            pos += nbytes + (4 - nbytes % 4) % 4
+            return a
+        s = cls()
+        for _ in range(nt):
+            w, h, c, is_float, typ = struct.unpack_from("<5I", buf, pos); pos += 20
+            s.textures.append(Texture(arr(np.float32 if is_float else np.uint8, w * h * c, (h, w, c)), typ))
+        for _ in range(nm):
+            v = struct.unpack_from("<3f3f9fI3ff6i", buf, pos); pos += 104
+            s.materials.append(Material(base=v[0:3], emission=v[3:6], metallic=v[6], roughness=v[7], transmission=v[8],
+                                        ior=v[9], anisotropic=v[10], aniso_rotation=v[11], clearcoat=v[12],
+                                        clearcoat_roughness=v[13], normal_scale=v[14], thin_transmission=bool(v[15]),
+                                        volume_color=v[16:19], volume_density=v[19], tex_base=v[20], tex_mr=v[21],
+                                        tex_transmission=v[22], tex_normal=v[23], tex_clearcoat=v[24], tex_emission=v[25]))
+        for _ in range(nme):
+            nv, nf = struct.unpack_from("<2I", buf, pos); pos += 8
+            p_ = arr(np.float32, nv * 3, (nv, 3)); n_ = arr(np.float32, nv * 3, (nv, 3))
+            t_ = arr(np.float32, nv * 4, (nv, 4)); u_ = arr(np.float32, nv * 2, (nv, 2))
+            f_ = arr(np.uint32, nf * 4, (nf, 4)); l_ = arr(np.int32, nf, (nf,))
+            s.meshes.append(Mesh(p_, n_, t_, u_, f_, l_))
+        s.nodes = []
+        for _ in range(nn):
+            parent, mesh = struct.unpack_from("<2i", buf, pos); pos += 8
+            s.nodes.append(Node(parent, mesh, arr(np.float32, 16, (4, 4)), arr(np.float32, 16, (4, 4))))
+        for _ in range(nl):
+            typ, mesh, tri, two, tex, radius, e0, e1, e2 = struct.unpack_from("<IiIIif3f", buf, pos); pos += 36
+            s.lights.append(Light(typ, mesh, tri, bool(two), tex, radius, (e0, e1, e2),
+                                  arr(np.float32, 16, (4, 4)), arr(np.float32, 16, (4, 4))))
+        return s
+
+    @classmethod
+    def load(cls, path) -> "Scene":
+        with open(path, "rb") as f:
+            return cls.frombytes(f.read())
+
     @property
     def n_triangles(self):
         return int(sum(len(self.meshes[n.mesh].faces) for n in self.nodes if n.mesh >= 0))

@@ -18,6 +18,8 @@
 //                   tonemapper) applied as tile-renderer.hpp:234-240 does, then output::writePPM
 //   yart_ref texture <image file> <C> <type 0|1|2> <c0,c1,..> <out.bin>   loadTexture<C>(bytes, len, type,
 //                   channels) of core/texture.hpp:62-92 (stb_image decode + gamma-2 re-encode): u32 w, h, C + bytes
+//   yart_ref writejpg <in image> <quality> <out.jpg>        stb_image_write's JPEG encoder (vendored by the reference
+//                   next to stb_image) on the decoded RGB of the input: quality <= 90 gives 4:2:0, above 4:4:4
 //   yart_ref hdr    <file.hdr> <out.bin>                    loadTextureHDR (core/texture.cpp:5-20): u32 w, h + floats
 //   yart_ref xform  <in.txt> <out.bin>   per input line "tx ty tz qx qy qz qw sx sy sz parent": the node Transform
 //                   of gltf.cpp:284-291 (float4x4::translation * rotationFromQuat * float4x4::scaling, inverse by
@@ -32,6 +34,7 @@
 #include <bsdf/luts.hpp>
 #include <core/tonemapping.hpp>
 #include <output/ppm.hpp>
+#include <stb_image_write.h>
 
 #include <cstdio>
 #include <fstream>
@@ -560,6 +563,16 @@ static int doTexture(const char* inPath, int C, int type, const char* chans, con
   throw std::runtime_error("C must be 1..4");
 }
 
+static int doWriteJpg(const char* inPath, int quality, const char* outPath) {
+  int w, h, n;
+  unsigned char* px = stbi_load(inPath, &w, &h, &n, 3);
+  if (!px) throw std::runtime_error(std::string("cannot decode ") + inPath);
+  const int ok = stbi_write_jpg(outPath, w, h, 3, px, quality);
+  stbi_image_free(px);
+  if (!ok) throw std::runtime_error("stbi_write_jpg failed");
+  return 0;
+}
+
 static int doHdr(const char* inPath, const char* outPath) {
   HDRTexture t = loadTextureHDR(inPath);
   std::ofstream o(outPath, std::ios::binary);
@@ -618,6 +631,7 @@ int main(int argc, char** argv) {
     if (mode == "bvh" && argc == 5) return doBvh(argv[2], size_t(std::atoi(argv[3])), argv[4]);
     if (mode == "texture" && argc == 7) return doTexture(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), argv[5], argv[6]);
     if (mode == "hdr" && argc == 4) return doHdr(argv[2], argv[3]);
+    if (mode == "writejpg" && argc == 5) return doWriteJpg(argv[2], std::atoi(argv[3]), argv[4]);
     if (mode == "xform" && argc == 4) return doXform(argv[2], argv[3]);
     if (mode == "tonemap" && argc == 8)
       return doTonemap(argv[2], unsigned(std::atoi(argv[3])), unsigned(std::atoi(argv[4])), argv[5], argv[6], argv[7]);

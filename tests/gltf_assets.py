@@ -1,4 +1,4 @@
-"""Test-side writers of the asset formats the glTF importer reads: PNG, Radiance .hdr, GLB / .gltf.
+"""Test-side writers of the asset formats the glTF importer reads: PNG, baseline JPEG, Radiance .hdr, GLB / .gltf.
 
 TEST INFRASTRUCTURE (used by tests/golden/make_gltf_goldens.py and tests/test_gltf_import.py); written from
 the format specifications. Nothing in the product imports this.
@@ -254,3 +254,137 @@ def quat_axis_angle(axis, angle):
     a = np.asarray(axis, np.float64); a = a / np.linalg.norm(a)
     s = np.sin(angle / 2)
     return [float(np.float32(a[0] * s)), float(np.float32(a[1] * s)), float(np.float32(a[2] * s)), float(np.float32(np.cos(angle / 2)))]
+
+
+# --------------------------------------------------------------------------------------------- JPEG
+_ZIGZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
+           28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54,
+           47, 55, 62, 63]
+
+
+class _BitWriter:
+    def __init__(self):
+        self.out = bytearray(); self.acc = 0; self.n = 0
+
+    def put(self, value, length):
+        self.acc = (self.acc << length) | (value & ((1 << length) - 1)); self.n += length
+        while self.n >= 8:
+            b = (self.acc >> (self.n - 8)) & 0xff
+            self.out.append(b)
+            if b == 0xff:
+                self.out.append(0)
+            self.n -= 8
+
+    def flush(self):
+        if self.n:
+            self.put((1 << (8 - self.n)) - 1, 8 - self.n)      # pad with 1-bits
+
+
+def jpeg_encode(pixels, sampling=((1, 1), (1, 1), (1, 1)), quant=(8, 12), restart=0, interleaved=True, jfif=True,
+                adobe_transform=None, component_ids=(1, 2, 3), fill_bytes=False):
+    """Baseline sequential JPEG (T.81) of an (h, w, 1|3) uint8 array whose channels are stored as given (Y / Cb / Cr,
+    or R / G / B for the RGB-id cases): the caller decides what the samples mean, the decoders under test must agree
+    on the result. Flat quantisation tables (luma, chroma steps), fixed-length Huffman codes (12 DC categories of
+    4 bits, the 162 AC symbols of 8 bits): any valid table is as good as another for a decoder test.
+    sampling: (h, v) per component; restart: MCUs per restart interval; interleaved=False writes one scan per
+    component."""
+    px = np.asarray(pixels, np.float64)
+    H, W, nc = px.shape
+    samp = list(sampling)[:nc]
+    hmax = max(h for h, v in samp); vmax = max(v for h, v in samp)
+    mcu_x = -(-W // (8 * hmax)); mcu_y = -(-H // (8 * vmax))
+    # component planes, subsampled by box averaging and padded by edge replication to the MCU grid
+    planes = []
+    for c, (h, v) in enumerate(samp):
+        fx, fy = hmax // h, vmax // v
+        cw, ch = -(-W * h // hmax), -(-H * v // vmax)
+        full = np.pad(px[..., c], ((0, ch * fy - H), (0, cw * fx - W)), mode="edge")
+        sub = full.reshape(ch, fy, cw, fx).mean(axis=(1, 3))
+        planes.append(np.pad(sub, ((0, mcu_y * v * 8 - ch), (0, mcu_x * h * 8 - cw)), mode="edge"))
+    k = np.arange(8)
+    D = np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16) * np.where(k[:, None] == 0, np.sqrt(1 / 8), np.sqrt(2 / 8))
+    dc_syms = list(range(12))
+    ac_syms = [0x00, 0xF0] + [(r << 4) | s for r in range(16) for s in range(1, 11)]
+    dc_code = {s: (i, 4) for i, s in enumerate(dc_syms)}
+    ac_code = {s: (i, 8) for i, s in enumerate(ac_syms)}
+
+    def seg(marker, body):
+        return bytes((0xFF, marker)) + struct.pack(">H", len(body) + 2) + body
+    out = bytearray(b"\xFF\xD8")
+    if jfif:
+        out += seg(0xE0, b"JFIF\0\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    if adobe_transform is not None:
+        out += seg(0xEE, b"Adobe\0" + bytes((100, 0, 0, 0, 0, adobe_transform)))
+    out += seg(0xFE, b"test asset")
+    for t, q in enumerate(quant):
+        out += seg(0xDB, bytes((t,)) + bytes([q] * 64))
+    out += seg(0xC0, struct.pack(">BHHB", 8, H, W, nc) +
+               b"".join(bytes((component_ids[c], (samp[c][0] << 4) | samp[c][1], 0 if c == 0 else 1)) for c in range(nc)))
+    out += seg(0xC4, bytes((0x00,)) + bytes([0, 0, 0, 12] + [0] * 12) + bytes(dc_syms))
+    out += seg(0xC4, bytes((0x10,)) + bytes([0] * 7 + [162] + [0] * 8) + bytes(ac_syms))
+    if restart:
+        out += seg(0xDD, struct.pack(">H", restart))
+
+    def category(v):
+        return int(abs(v)).bit_length()
+
+    def encode_block(bw, plane, bx, by, q, pred):
+        blk = plane[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] - 128.0
+        coef = np.rint(D @ blk @ D.T / q).astype(np.int64).reshape(64)
+        zz = [int(coef[i]) for i in _ZIGZAG]
+        diff = zz[0] - pred
+        s = category(diff)
+        bw.put(*dc_code[s])
+        if s:
+            bw.put(diff if diff >= 0 else diff + (1 << s) - 1, s)
+        run = 0
+        last = max((i for i in range(1, 64) if zz[i]), default=0)
+        for i in range(1, last + 1):
+            if zz[i] == 0:
+                run += 1
+                continue
+            while run > 15:
+                bw.put(*ac_code[0xF0]); run -= 16
+            v = max(-1023, min(1023, zz[i]))
+            s = category(v)
+            bw.put(*ac_code[(run << 4) | s])
+            bw.put(v if v >= 0 else v + (1 << s) - 1, s)
+            run = 0
+        if last < 63:
+            bw.put(*ac_code[0x00])
+        return zz[0]
+
+    def scan(comps):
+        nonlocal out
+        out += seg(0xDA, bytes((len(comps),)) + b"".join(bytes((component_ids[c], 0x00)) for c in comps) + bytes((0, 63, 0)))
+        bw = _BitWriter()
+        pred = {c: 0 for c in comps}
+        units = []
+        if len(comps) == 1:
+            c = comps[0]
+            h, v = samp[c]
+            bwid = -(-(-(-W * h // hmax)) // 8); bhei = -(-(-(-H * v // vmax)) // 8)
+            units = [[(c, i, j)] for j in range(bhei) for i in range(bwid)]
+        else:
+            for j in range(mcu_y):
+                for i in range(mcu_x):
+                    units.append([(c, i * samp[c][0] + x, j * samp[c][1] + y) for c in comps
+                                  for y in range(samp[c][1]) for x in range(samp[c][0])])
+        rst = 0
+        for n, unit in enumerate(units):
+            for c, bx, by in unit:
+                pred[c] = encode_block(bw, planes[c], bx, by, quant[0 if c == 0 else 1], pred[c])
+            if restart and (n + 1) % restart == 0 and n + 1 < len(units):
+                bw.flush()
+                out += bw.out + (b"\xFF" if fill_bytes else b"") + bytes((0xFF, 0xD0 + rst % 8))
+                bw = _BitWriter(); rst += 1
+                pred = {c: 0 for c in comps}
+        bw.flush()
+        out += bw.out
+    if interleaved or nc == 1:
+        scan(list(range(nc)))
+    else:
+        for c in range(nc):
+            scan([c])
+    out += b"\xFF\xD9"
+    return bytes(out)

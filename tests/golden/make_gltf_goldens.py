@@ -6,13 +6,17 @@ Runs only where /root/reference is mounted (the build container):
 Inputs (written by tests/gltf_assets.py, all small):
     png_<case>.png          PNG files covering colour types 0/2/3/4/6, bit depths 1-16, every scanline filter, Adam7
                             interlace, tRNS keys and palette alpha, split IDAT
+    jpg_<case>.jpg          baseline JPEG files from two encoders (stb_image_write via `yart_ref writejpg`, and
+                            tests/gltf_assets.jpeg_encode): 4:4:4 / 4:2:0 / 4:2:2 / 4:4:0 / 4:1:1 / odd factors, grey, restart
+                            intervals with fill bytes, one scan per component, RGB component ids, Adobe / JFIF signalling,
+                            1- and 2-pixel-wide images, saturated chroma
     env_rle.hdr / env_flat.hdr / env_tiny.hdr   Radiance files (RLE scanlines, flat, width < 8)
     xform.txt               node T / R / S rows with parent links
     gallery.glb             a small scene using every material extension the importer maps, merged primitives, strided /
                             normalised / u8 / u16 accessors, generated indices, nested and matrix nodes, an instanced light mesh
     gallery.txt             camera / render parameters
 Expected outputs (the reference's own code, through oracle/_ref/yart_ref):
-    png_<case>.<C><type>.tex    loadTexture<C>(file, type, channels) (core/texture.hpp:62-92): u32 w, h, C + bytes
+    png_<case>.<C><type>.tex, jpg_<case>.<C><type>.tex    loadTexture<C>(file, type, channels) (core/texture.hpp:62-92): u32 w, h, C + bytes
     env_*.hdrtex                loadTextureHDR (core/texture.cpp:5-20): u32 w, h + float RGB
     xform.bin                   Transform(T*R*S) and node.transform * globalTransform per row (gltf.cpp:284-293)
     gallery.f32                 the reference's render of the scene the importer made of gallery.glb + env_rle.hdr
@@ -68,6 +72,49 @@ def png_cases():
                                     trns=bytes((0, 128)), interlace=True),
         "pal1": ga.png_encode(rng.integers(0, 2, (5, 3, 1)), 3, depth=1, palette=[[255, 0, 0], [0, 0, 255]]),
     }
+    return cases
+
+
+def jpeg_cases(tmp_png):
+    """Baseline JPEG files from two encoders: stb_image_write (through `yart_ref writejpg`: 4:2:0 and 4:4:4) and
+    tests/gltf_assets.jpeg_encode (other samplings, restart intervals, several scans, colour-space signalling)."""
+    rng = np.random.default_rng(21)
+    h, w = 37, 53                                        # not multiples of the MCU size
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 70 * np.sin(xx / 5.0) + 40 * np.cos(yy / 3.0), 128 + 60 * np.sin((xx + yy) / 7.0),
+                    128 + 80 * np.cos(xx / 4.0 - yy / 6.0)], -1) + rng.normal(0, 8, (h, w, 3))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    with open(tmp_png, "wb") as f:
+        f.write(ga.png_encode(img, 2))
+    cases = {}
+    for name, q in (("stb420", 75), ("stb444", 95), ("stb420_q20", 20)):
+        out = tmp_png + ".jpg"
+        subprocess.run([REF, "writejpg", tmp_png, str(q), out], check=True)
+        cases[name] = open(out, "rb").read()
+        os.remove(out)
+    e = ga.jpeg_encode
+    cases.update({
+        "444": e(img),
+        "420_rst": e(img, sampling=((2, 2), (1, 1), (1, 1)), restart=3, fill_bytes=True),
+        "422": e(img, sampling=((2, 1), (1, 1), (1, 1)), quant=(3, 5)),
+        "440": e(img, sampling=((1, 2), (1, 1), (1, 1)), restart=1),
+        "411": e(img, sampling=((4, 1), (1, 1), (1, 1))),
+        "chroma_v4": e(img, sampling=((1, 4), (1, 2), (1, 1))),
+        "gray": e(img[..., :1]),
+        "gray_h2v2": e(img[..., :1], sampling=((2, 2),)),
+        "scans": e(img, sampling=((2, 2), (1, 1), (1, 1)), interleaved=False, restart=5),
+        "rgb_ids": e(img, component_ids=(ord("R"), ord("G"), ord("B")), sampling=((2, 1), (1, 1), (2, 1))),
+        "adobe0": e(img, jfif=False, adobe_transform=0),
+        "adobe0_jfif": e(img, jfif=True, adobe_transform=0),
+        "adobe1": e(img, jfif=False, adobe_transform=1, sampling=((2, 2), (1, 1), (1, 1))),
+        "nojfif": e(img, jfif=False),
+        "w1": e(img[:5, :1], sampling=((2, 2), (1, 1), (1, 1))),
+        "w2": e(img[:3, :2], sampling=((2, 2), (1, 1), (1, 1))),
+        "w2_422": e(img[:9, :2], sampling=((2, 1), (1, 1), (1, 1))),
+        "sat": e(np.where((xx // 6 + yy // 5)[..., None] % 2 == 0, np.array([250, 10, 250]), np.array([5, 250, 8])).astype(np.uint8),
+                 sampling=((2, 2), (1, 1), (1, 1)), quant=(2, 2)),      # saturated chroma: exercises the clamps
+    })
+    os.remove(tmp_png)
     return cases
 
 
@@ -199,6 +246,13 @@ def main():
             if tag != "4s" and name not in ("rgba8", "rgb16_key", "pal8", "graya8"):
                 continue                   # the channel-selection variants on a few files only
             subprocess.run([REF, "texture", path, str(c), str(typ), ch, os.path.join(OUT, f"png_{name}.{tag}.tex")], check=True)
+    for name, data in jpeg_cases(os.path.join(OUT, "_src.png")).items():
+        path = os.path.join(OUT, f"jpg_{name}.jpg")
+        with open(path, "wb") as f:
+            f.write(data)
+        for tag in ("4s",) + (("3n", "2n") if name in ("stb420", "422") else ()):
+            c, typ, ch = TEX_KINDS[tag]
+            subprocess.run([REF, "texture", path, str(c), str(typ), ch, os.path.join(OUT, f"jpg_{name}.{tag}.tex")], check=True)
     rgbe = ga.rgbe_from_float(sky(16))
     hdrs = {"env_rle": ga.hdr_encode(rgbe, rle=True), "env_flat": ga.hdr_encode(rgbe, rle=False, magic=b"#?RGBE"),
             "env_tiny": ga.hdr_encode(ga.rgbe_from_float(sky(6)), rle=False)}

@@ -52,10 +52,11 @@ PNG_TEX = sorted(f[:-4] for f in os.listdir(G) if f.endswith(".tex")) if os.path
 
 
 @pytest.mark.parametrize("case", PNG_TEX)
-def test_png_texture_equals_reference_loadtexture(api, tmp_path, case):
-    """Embedded PNG -> texture bytes == the reference's loadTexture<C> on the same file (stb_image + gamma 2)."""
+def test_image_texture_equals_reference_loadtexture(api, tmp_path, case):
+    """Embedded PNG / baseline JPEG -> texture bytes == the reference's loadTexture<C> on the same file
+    (stb_image decode + gamma-2 re-encode), byte for byte."""
     name, kind = case.rsplit(".", 1)
-    with open(os.path.join(G, name + ".png"), "rb") as f:
+    with open(os.path.join(G, name + (".png" if name.startswith("png_") else ".jpg")), "rb") as f:
         png = f.read()
     b = ga.GltfBuilder()
     mat = b.material(**_material_for(kind, b.texture(b.image(png))))
@@ -232,12 +233,18 @@ def _expect_error(api, path, fragment, tmp_path):
 
 
 def test_unsupported_or_broken_assets_fail_loudly(api, tmp_path):
-    # JPEG image: refused, not approximated
+    # progressive JPEG (SOF2): refused, not approximated
     b = ga.GltfBuilder()
-    jpeg = bytes((0xFF, 0xD8, 0xFF, 0xE0)) + bytes(64)
+    jpeg = ga.jpeg_encode(np.full((8, 8, 3), 128, np.uint8)).replace(b"\xFF\xC0", b"\xFF\xC2", 1)
     b.node(_triangle_mesh(b, b.material(pbrMetallicRoughness={"baseColorTexture": {"index": b.texture(b.image(jpeg, mime="image/jpeg"))}})), root=True)
     p = os.path.join(tmp_path, "jpeg.glb"); b.write_glb(p)
-    _expect_error(api, p, "JPEG", tmp_path)
+    _expect_error(api, p, "progressive", tmp_path)
+    # truncated JPEG
+    b = ga.GltfBuilder()
+    jpeg = ga.jpeg_encode(np.full((16, 16, 3), 99, np.uint8))[:200]
+    b.node(_triangle_mesh(b, b.material(pbrMetallicRoughness={"baseColorTexture": {"index": b.texture(b.image(jpeg, mime="image/jpeg"))}})), root=True)
+    p = os.path.join(tmp_path, "jpegcut.glb"); b.write_glb(p)
+    _expect_error(api, p, "jpeg", tmp_path)
     # missing NORMAL: the reference dereferences the missing attribute
     b = ga.GltfBuilder()
     pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)

@@ -23,8 +23,9 @@
 // samplers (wrap is always repeat), vertex colours, skins, animations, morph targets.
 // Node `matrix` properties are decomposed to T / R / S first (fastgltf's DecomposeNodeMatrices
 // option); that decomposition is restated from the glTF specification, so matrix-valued nodes may
-// differ from the reference in the last bits of the node transform. Sparse accessors and JPEG
-// images are refused with an error (image_decode.hpp says why).
+// differ from the reference in the last bits of the node transform. Embedded PNG and baseline JPEG
+// images are decoded to the reference's bytes (image_decode.hpp); progressive JPEG and sparse accessors
+// are refused with an error.
 #pragma once
 #include <algorithm>
 #include <cctype>

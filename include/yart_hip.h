@@ -119,8 +119,16 @@ typedef struct YartRenderParams {
    * schedule (stop_sample 0 = samples). With start_sample > 0 the output buffer must hold the frame
    * accumulated so far and is blended into, exactly as an uninterrupted render would continue. */
   uint32_t start_sample, stop_sample;
-  uint32_t reserved[2];
+  /* Per-pixel estimator (core/estimator.hpp): the reference's Integrator::render picks one at compile time
+   * (cpu/integrator.cpp:17-18: GMoNEstimator(samples, 15) as shipped, MeanEstimator in the commented line);
+   * MoN and GMoNb take the same (samples, 15). 0 keeps the shipped behaviour. */
+  uint32_t estimator;        /* YART_ESTIMATOR_* */
+  uint32_t reserved[1];
 } YartRenderParams;
+#define YART_ESTIMATOR_GMON 0u      /* core/estimator.hpp:148-198 */
+#define YART_ESTIMATOR_MEAN 1u      /* :29-46 */
+#define YART_ESTIMATOR_MON 2u       /* :53-92 */
+#define YART_ESTIMATOR_GMONB 3u     /* :94-146 */
 
 #define YART_FLAG_MEGAKERNEL 1u     /* single-kernel integrator instead of the wavefront pipeline */
 #define YART_FLAG_NO_REFILL 16u     /* one-ray-per-lane lean kernels instead of the ones with in-wave ray

@@ -18,6 +18,9 @@
 //                   tonemapper) applied as tile-renderer.hpp:234-240 does, then output::writePPM
 //   yart_ref texture <image file> <C> <type 0|1|2> <c0,c1,..> <out.bin>   loadTexture<C>(bytes, len, type,
 //                   channels) of core/texture.hpp:62-92 (stb_image decode + gamma-2 re-encode): u32 w, h, C + bytes
+//   yart_ref estimator <kind 0 GMoN|1 Mean|2 MoN|3 GMoNb> <spp> <in.f32> <out.f32>   the reference's estimator classes
+//                   (core/estimator.hpp, constructed as cpu/integrator.cpp:17-18 does: (spp, 15) / (spp)) fed groups of
+//                   spp RGB samples in order; one getValue() per group
 //   yart_ref writejpg <in image> <quality> <out.jpg>        stb_image_write's JPEG encoder (vendored by the reference
 //                   next to stb_image) on the decoded RGB of the input: quality <= 90 gives 4:2:0, above 4:4:4
 //   yart_ref hdr    <file.hdr> <out.bin>                    loadTextureHDR (core/texture.cpp:5-20): u32 w, h + floats
@@ -33,6 +36,7 @@
 #include <bsdf/parametric.hpp>
 #include <bsdf/luts.hpp>
 #include <core/tonemapping.hpp>
+#include <core/estimator.hpp>
 #include <output/ppm.hpp>
 #include <stb_image_write.h>
 
@@ -563,6 +567,33 @@ static int doTexture(const char* inPath, int C, int type, const char* chans, con
   throw std::runtime_error("C must be 1..4");
 }
 
+static int doEstimator(int kind, unsigned spp, const char* inPath, const char* outPath) {
+  std::ifstream f(inPath, std::ios::binary);
+  if (!f) throw std::runtime_error(std::string("cannot open ") + inPath);
+  std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  const float* smp = reinterpret_cast<const float*>(raw.data());
+  const size_t groups = raw.size() / 12 / spp;
+  std::ofstream o(outPath, std::ios::binary);
+  for (size_t g = 0; g < groups; g++) {
+    std::unique_ptr<Estimator> e;
+    switch (kind) {
+      case 0: e = std::make_unique<GMoNEstimator>(int32_t(spp), 15); break;
+      case 1: e = std::make_unique<MeanEstimator>(spp); break;
+      case 2: e = std::make_unique<MoNEstimator>(int32_t(spp), 15); break;
+      case 3: e = std::make_unique<GMoNbEstimator>(int32_t(spp), 15); break;
+      default: throw std::runtime_error("estimator kind must be 0..3");
+    }
+    for (unsigned k = 0; k < spp; k++) {
+      const float* p = smp + (g * spp + k) * 3;
+      e->addSample(float3(p[0], p[1], p[2]));
+    }
+    const float3 v = e->getValue();
+    const float q[3] = {v[0], v[1], v[2]};
+    o.write(reinterpret_cast<const char*>(q), 12);
+  }
+  return 0;
+}
+
 static int doWriteJpg(const char* inPath, int quality, const char* outPath) {
   int w, h, n;
   unsigned char* px = stbi_load(inPath, &w, &h, &n, 3);
@@ -631,6 +662,7 @@ int main(int argc, char** argv) {
     if (mode == "bvh" && argc == 5) return doBvh(argv[2], size_t(std::atoi(argv[3])), argv[4]);
     if (mode == "texture" && argc == 7) return doTexture(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), argv[5], argv[6]);
     if (mode == "hdr" && argc == 4) return doHdr(argv[2], argv[3]);
+    if (mode == "estimator" && argc == 6) return doEstimator(std::atoi(argv[2]), unsigned(std::atoi(argv[3])), argv[4], argv[5]);
     if (mode == "writejpg" && argc == 5) return doWriteJpg(argv[2], std::atoi(argv[3]), argv[4]);
     if (mode == "xform" && argc == 4) return doXform(argv[2], argv[3]);
     if (mode == "tonemap" && argc == 8)

@@ -12,6 +12,7 @@ and, for the tonemap / output step (reference core/tonemapping.hpp + output/ppm.
 `yart_ref tonemap`), from the `material` frame (HDR values from 0 to the sun's brightness):
     material.agx_<look>.f32   AgX-mapped RGBA32F frame for look in none / golden / punchy
     material.agx_<look>.ppm   the P6 file output::writePPM makes of it ("raw" = no tonemapper)
+and estimator/spp<N>.in.f32 + estimator/spp<N>.k<kind>.f32 (see estimator_goldens).
 All files are data: inputs and the reference's outputs for them.
 """
 import os
@@ -44,6 +45,39 @@ def _waves():
     return s, p
 
 
+ESTIMATOR_SPPS = (1, 4, 5, 14, 15, 16, 25, 35, 64, 155, 256)
+
+
+def estimator_goldens():
+    """estimator/spp<N>.in.f32: groups of N RGB samples (heavy-tailed, with NaN / negative / inf / zero samples and
+    whole buckets rejected); estimator/spp<N>.k<kind>.f32: the reference's GMoN / Mean / MoN / GMoNb value per group
+    (core/estimator.hpp classes through `yart_ref estimator`)."""
+    import numpy as np
+    out = os.path.join(HERE, "estimator")
+    os.makedirs(out, exist_ok=True)
+    rng = np.random.default_rng(17)
+    for spp in ESTIMATOR_SPPS:
+        groups = 24
+        x = (rng.lognormal(-1.0, 1.2, (groups, spp, 3)) * rng.uniform(0.2, 2.0, (groups, 1, 3))).astype(np.float32)
+        fire = rng.random((groups, spp, 1)) < 0.03
+        x = np.where(fire, x * 300.0, x).astype(np.float32)
+        bad = rng.random((groups, spp)) < 0.06
+        kinds = rng.integers(0, 4, (groups, spp))
+        x[bad & (kinds == 0), 0] = np.nan
+        x[bad & (kinds == 1), 1] = -0.25
+        x[bad & (kinds == 2), 2] = np.inf
+        x[bad & (kinds == 3)] = 0.0
+        x[0] = 0.0                                     # an all-black pixel: 0 / 0 paths
+        if spp > 1:
+            x[1, ::2] = np.nan                         # every other sample rejected (whole buckets when m is even-strided)
+            x[2, :, :] = x[2, :1, :]                   # constant pixel: Gini = 0
+            x[3] = -1.0                                # everything negative: GMoN rejects all, the others keep them
+        base = os.path.join(out, f"spp{spp}")
+        x.tofile(base + ".in.f32")
+        for kind in range(4):
+            subprocess.run([REF, "estimator", str(kind), str(spp), base + ".in.f32", base + f".k{kind}.f32"], check=True)
+
+
 def main():
     if not os.path.exists(REF):
         raise SystemExit("oracle/_ref/yart_ref missing: run `make -C oracle ref` first")
@@ -58,6 +92,7 @@ def main():
                        stdout=subprocess.DEVNULL)
         print(name, {k: os.path.getsize(base + k) for k in (".yscn", ".kat.json", ".f32")})
     subprocess.run([REF, "luts", os.path.join(HERE, "ref_tables.bin")], check=True)
+    estimator_goldens()
     base = os.path.join(HERE, "material")
     w, h = 96, 64
     for look, tag in (("none", "none"), ("golden", "golden"), ("punchy", "punchy"), ("-", "raw")):

@@ -427,8 +427,39 @@ static int doTonemap(const char* in, unsigned w, unsigned h, const std::string& 
   return 0;
 }
 
+// estimator: csrc/estimator.hpp (the functions k_gmon_blend runs, compiled for the host) over groups of `spp`
+// RGB samples; sample k goes to bucket k mod m in increasing k, exactly as the kernel's lanes do.
+static int doEstimator(int kind, unsigned spp, const char* in, const char* out) {
+  FILE* f = std::fopen(in, "rb");
+  if (!f) { std::fprintf(stderr, "estimator: cannot open input\n"); return 2; }
+  std::vector<float> smp;
+  float buf[3];
+  while (std::fread(buf, 4, 3, f) == 3) smp.insert(smp.end(), buf, buf + 3);
+  std::fclose(f);
+  const size_t groups = smp.size() / 3 / spp;
+  std::vector<float> res(groups * 3);
+  const int m = estimatorBuckets(kind, int32_t(spp));
+  for (size_t g = 0; g < groups; g++) {
+    f3 acc[kGmonMax]; uint32_t cnt[kGmonMax];
+    for (int b = 0; b < m; b++) {
+      acc[b] = mk3(0); cnt[b] = 0;
+      for (unsigned k = unsigned(b); k < spp; k += unsigned(m)) {
+        const float* p = &smp[(g * spp + k) * 3];
+        const f3 v = mk3(p[0], p[1], p[2]);
+        if (estimatorAccepts(kind, v)) { acc[b] += v; cnt[b]++; }
+      }
+    }
+    const f3 v = estimatorFinish(kind, acc, cnt, m, spp);
+    res[3 * g] = v.x; res[3 * g + 1] = v.y; res[3 * g + 2] = v.z;
+  }
+  f = std::fopen(out, "wb"); std::fwrite(res.data(), 4, res.size(), f); std::fclose(f);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc == 2 && std::string(argv[1]) == "selftest") return doSelfTest();
+  if (argc == 6 && std::string(argv[1]) == "estimator")
+    return doEstimator(std::atoi(argv[2]), unsigned(std::atoi(argv[3])), argv[4], argv[5]);
   if (argc == 8 && std::string(argv[1]) == "tonemap")
     return doTonemap(argv[2], unsigned(std::atoi(argv[3])), unsigned(std::atoi(argv[4])), argv[5], argv[6], argv[7]);
   if (argc != 5) {

@@ -97,7 +97,7 @@ class RenderParams(C.Structure):
                 ("max_wave_samples", C.c_uint32), ("tile_size", C.c_uint32), ("max_depth", C.c_uint32),
                 ("background", C.c_float * 3), ("rank", C.c_uint32), ("world_size", C.c_uint32),
                 ("flags", C.c_uint32), ("start_sample", C.c_uint32), ("stop_sample", C.c_uint32),
-                ("reserved", C.c_uint32 * 2)]
+                ("estimator", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
 
 class Stats(C.Structure):
@@ -112,6 +112,10 @@ class Stats(C.Structure):
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# YartRenderParams.estimator (core/estimator.hpp; the reference picks one at compile time, integrator.cpp:17-18)
+ESTIMATOR_GMON, ESTIMATOR_MEAN, ESTIMATOR_MON, ESTIMATOR_GMONB = 0, 1, 2, 3
 
 
 class ImportOptions(C.Structure):
@@ -215,6 +219,7 @@ def make_params(p: dict, rank=0, world_size=1, flags=0) -> RenderParams:
     r.background = _f(p.get("background", (0, 0, 0)), 3)
     r.rank, r.world_size, r.flags = int(rank), int(world_size), int(flags)
     r.start_sample, r.stop_sample = int(p.get("start_sample", 0)), int(p.get("stop_sample", 0))
+    r.estimator = int(p.get("estimator", ESTIMATOR_GMON))
     return r
 
 

@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(MegaArgs a) {
 struct GmonArgs {
   const float* L;
   const uint32_t* pixels;
-  uint32_t nPixels, spp, width, pad;
+  uint32_t nPixels, spp, width;
+  int kind;                    // EstimatorKind
   float exposureScale, wCurrent, wWave, pad1;
   float* hdr;                  // RGBA32F, width * height
 };
@@ -149,13 +150,13 @@ __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
   const uint32_t sub = threadIdx.x & (kGmonLanes - 1), lp = threadIdx.x / kGmonLanes;
   const uint32_t pi = blockIdx.x * kGmonPixPerBlock + lp;
   const bool valid = pi < a.nPixels;
-  const int m = gmonBuckets(int32_t(a.spp));
+  const int m = estimatorBuckets(a.kind, int32_t(a.spp));
   if (valid && int(sub) < m) {
     f3 acc = mk3(0); uint32_t cnt = 0;
     const float* p = a.L + size_t(pi) * a.spp * 3;
     for (uint32_t s = sub; s < a.spp; s += uint32_t(m)) {       // bucket k mod m, increasing k
       f3 v = mk3(p[s * 3], p[s * 3 + 1], p[s * 3 + 2]) * a.exposureScale;
-      if (gmonAccepts(v)) { acc += v; cnt++; }
+      if (estimatorAccepts(a.kind, v)) { acc += v; cnt++; }
     }
     sAcc[lp][sub][0] = acc.x; sAcc[lp][sub][1] = acc.y; sAcc[lp][sub][2] = acc.z;
     sAcc[lp][sub][3] = __uint_as_float(cnt);
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
       acc[b] = mk3(sAcc[lp][b][0], sAcc[lp][b][1], sAcc[lp][b][2]);
       cnt[b] = __float_as_uint(sAcc[lp][b][3]);
     }
-    f3 v = gmonFinish(acc, cnt, m);
+    f3 v = estimatorFinish(a.kind, acc, cnt, m, a.spp);
     const uint32_t pk = a.pixels[pi];
     float* o = a.hdr + (size_t(pk >> 16) * a.width + (pk & 0xffffu)) * 4;
     // m_hdrBuffer = current * wCurrent + wave * wWave   (tile-renderer.hpp:230)
@@ -362,6 +363,7 @@ void validate(const YartCameraDesc* cam, const YartRenderParams* p) {
   require(p->max_depth > 0, "max_depth must be > 0");
   require(p->start_sample < p->samples && (p->stop_sample == 0 || (p->stop_sample > p->start_sample && p->stop_sample <= p->samples)),
           "start_sample / stop_sample out of range");
+  require(p->estimator <= YART_ESTIMATOR_GMONB, "estimator must be one of YART_ESTIMATOR_*");
 }
 
 RenderConst makeRenderConst(const YartRenderParams& p) {
@@ -575,6 +577,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       GmonArgs g{};
       g.L = s.L.p; g.pixels = s.pixels.p + c0; g.nPixels = n; g.spp = uint32_t(waveSamples); g.width = W;
       g.exposureScale = cam.exposureScale; g.wCurrent = wCurrent; g.wWave = wWave; g.hdr = dOut;
+      g.kind = int(p.estimator);
       tGmon.begin(stream);
       hipLaunchKernelGGL(k_gmon_blend, dim3((n + kGmonPixPerBlock - 1) / kGmonPixPerBlock), dim3(kBlock), 0, stream, g);
       HIP_CHECK(hipGetLastError());

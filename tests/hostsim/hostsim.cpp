@@ -456,8 +456,37 @@ static int doEstimator(int kind, unsigned spp, const char* in, const char* out) 
   return 0;
 }
 
+// bvhcheck: the task-parallel BVH build against the plain recursion, every mesh of a scene, byte for byte
+static int doBvhCheck(const char* scenePath, unsigned threads) {
+  auto loaded = loadSceneFile(scenePath);
+  double msSerial = 0, msParallel = 0;
+  size_t nodes = 0, tris = 0;
+  for (uint32_t m = 0; m < loaded->desc.n_meshes; m++) {
+    const YartMeshDesc& md = loaded->desc.meshes[m];
+    SahBvhBuilder a, b;
+    a.setThreads(1); b.setThreads(threads);
+    auto t0 = std::chrono::steady_clock::now();
+    a.build(md.positions, md.faces, 4, md.n_faces);
+    auto t1 = std::chrono::steady_clock::now();
+    b.build(md.positions, md.faces, 4, md.n_faces);
+    auto t2 = std::chrono::steady_clock::now();
+    msSerial += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    msParallel += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    if (a.nodes.size() != b.nodes.size() || std::memcmp(a.nodes.data(), b.nodes.data(), a.nodes.size() * sizeof(BvhNode)) != 0 ||
+        a.indices != b.indices) {
+      std::fprintf(stderr, "bvhcheck: mesh %u differs between 1 and %u threads\n", m, threads);
+      return 3;
+    }
+    nodes += a.nodes.size(); tris += md.n_faces;
+  }
+  std::printf("{\"bvhcheck\": \"ok\", \"meshes\": %u, \"triangles\": %zu, \"nodes\": %zu, \"threads\": %u, \"ms_serial\": %.1f, \"ms_parallel\": %.1f}\n",
+              loaded->desc.n_meshes, tris, nodes, threads, msSerial, msParallel);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc == 2 && std::string(argv[1]) == "selftest") return doSelfTest();
+  if (argc == 4 && std::string(argv[1]) == "bvhcheck") return doBvhCheck(argv[2], unsigned(std::atoi(argv[3])));
   if (argc == 6 && std::string(argv[1]) == "estimator")
     return doEstimator(std::atoi(argv[2]), unsigned(std::atoi(argv[3])), argv[4], argv[5]);
   if (argc == 8 && std::string(argv[1]) == "tonemap")

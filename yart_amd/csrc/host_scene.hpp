@@ -8,6 +8,7 @@
 // camera.hpp:25-59) with the same float arithmetic, so the kernels start from
 // bit-identical constants.
 #pragma once
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -179,6 +180,10 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
     md.nTris = m.n_faces; md.nVerts = m.n_vertices;
 
     SahBvhBuilder b;
+    {   // YART_BVH_THREADS: worker threads of the build (default: all hardware threads, at most 32; 1 = serial)
+      const char* e = std::getenv("YART_BVH_THREADS");
+      b.setThreads(e ? unsigned(std::atoi(e)) : 0u);
+    }
     b.build(m.positions, m.faces, 4, m.n_faces);
     md.nNodes = uint32_t(b.nodes.size());
     im.bvhNodes.insert(im.bvhNodes.end(), b.nodes.begin(), b.nodes.end());

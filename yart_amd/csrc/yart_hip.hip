@@ -632,6 +632,18 @@ int guarded(F&& f) {
 
 }  // namespace
 
+namespace {
+std::unique_ptr<LoadedScene> importGltf(const char* path, const YartImportOptions* opts) {
+  auto loaded = gltf::loadGltf(path);
+  if (opts) {
+    const float radius = opts->env_radius > 0.0f ? opts->env_radius : 100.0f;      // frontend main.cpp:82
+    if (opts->env_hdr_path && opts->env_hdr_path[0]) gltf::addImageEnvironment(*loaded, opts->env_hdr_path, radius);
+    if (opts->uniform_env) gltf::addUniformEnvironment(*loaded, opts->uniform_emission, radius);
+  }
+  return loaded;
+}
+}  // namespace
+
 extern "C" {
 
 int yart_hip_abi_version(void) { return YART_HIP_ABI_VERSION; }
@@ -658,18 +670,6 @@ int yart_hip_scene_load(const char* path, int device, YartScene** out) {
     *out = createScene(loaded->desc, device);
   });
 }
-
-namespace {
-std::unique_ptr<LoadedScene> importGltf(const char* path, const YartImportOptions* opts) {
-  auto loaded = gltf::loadGltf(path);
-  if (opts) {
-    const float radius = opts->env_radius > 0.0f ? opts->env_radius : 100.0f;      // frontend main.cpp:82
-    if (opts->env_hdr_path && opts->env_hdr_path[0]) gltf::addImageEnvironment(*loaded, opts->env_hdr_path, radius);
-    if (opts->uniform_env) gltf::addUniformEnvironment(*loaded, opts->uniform_emission, radius);
-  }
-  return loaded;
-}
-}  // namespace
 
 int yart_hip_scene_load_gltf(const char* path, const YartImportOptions* opts, int device, YartScene** out) {
   return guarded([&] {

@@ -35,12 +35,23 @@ class DeviceScene {
  public:
   explicit DeviceScene(const YartSceneDesc& desc, int device = -1) { check(yart_hip_scene_create(&desc, device, &h_)); }
   explicit DeviceScene(const std::string& yscnPath, int device = -1) { check(yart_hip_scene_load(yscnPath.c_str(), device, &h_)); }
+  // a glTF 2.0 / GLB asset, as gltf::load + the frontend's environment light (src/gltf/gltf.cpp:319-358, src/main.cpp:78-86)
+  static DeviceScene fromGltf(const std::string& path, const std::string& envHdrPath = "", float envRadius = 100.0f, int device = -1) {
+    YartImportOptions o{};
+    o.env_hdr_path = envHdrPath.empty() ? nullptr : envHdrPath.c_str();
+    o.env_radius = envRadius;
+    YartScene* h = nullptr;
+    check(yart_hip_scene_load_gltf(path.c_str(), &o, device, &h));
+    return DeviceScene(h);
+  }
+  DeviceScene(DeviceScene&& other) noexcept : h_(other.h_) { other.h_ = nullptr; }
   DeviceScene(const DeviceScene&) = delete;
   DeviceScene& operator=(const DeviceScene&) = delete;
   ~DeviceScene() { yart_hip_scene_destroy(h_); }
   YartScene* handle() const { return h_; }
 
  private:
+  explicit DeviceScene(YartScene* h) : h_(h) {}
   YartScene* h_ = nullptr;
 };
 
@@ -73,6 +84,8 @@ class HipTileRenderer {
   uint32_t samples = 64, firstWaveSamples = 64, maxWaveSamples = 128, tileSize = 64;
   uint32_t maxDepth = 30;                   // RayIntegrator::m_maxDepth (ray-integrator.hpp:14)
   float backgroundColor[3] = {0, 0, 0};
+  uint32_t estimator = YART_ESTIMATOR_GMON; // core/estimator.hpp class (integrator.cpp:17-18 fixes it at compile time)
+  int tonemapLook = -1;                     // TileRenderer::tonemapper: -1 none (linear HDR), 0 AgX none, 1 golden, 2 punchy
   const DeviceScene* scene = nullptr;
   RenderCallback<RenderData> onRenderComplete, onRenderAborted;
 
@@ -102,7 +115,10 @@ class HipTileRenderer {
       p.max_wave_samples = maxWaveSamples; p.tile_size = tileSize; p.max_depth = maxDepth;
       for (int i = 0; i < 3; i++) p.background[i] = backgroundColor[i];
       p.rank = 0; p.world_size = 1;
+      p.estimator = estimator;
       check(yart_hip_render(scene->handle(), &camera_, &p, buffer_.data(), &st));
+      if (tonemapLook >= 0)                   // tile-renderer.hpp:234-239, on the whole frame
+        check(yart_hip_tonemap_host(buffer_.data(), buffer_.width(), buffer_.height(), tonemapLook, buffer_.data(), nullptr));
     }
     auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0);
     stats_ = st;

@@ -60,3 +60,22 @@ def test_product_does_not_reference_oracle():
                 if s.startswith(("//", "#", "*", '"""')) or "oracle/" not in s:
                     continue
                 assert "include" not in s and "import" not in s and "subprocess" not in s, (path, s)
+
+
+def test_cpp_mirror_header_compiles_and_links(built, tmp_path):
+    """include/yart_hip.hpp (the C++ face of the ABI: DeviceScene / HipTileRenderer with the reference's knob
+    names) compiles as C++17 and links against the library."""
+    import subprocess
+    src = os.path.join(tmp_path, "m.cpp")
+    with open(src, "w") as f:
+        f.write('#include "yart_hip.hpp"\n'
+                "int main() { yart::hip::Buffer b(4, 4); YartCameraDesc c{}; yart::hip::HipTileRenderer r(std::move(b), c);\n"
+                "  r.estimator = YART_ESTIMATOR_MON; r.tonemapLook = 1; r.samples = 4;\n"
+                "  try { auto s = yart::hip::DeviceScene::fromGltf(\"/nonexistent.glb\"); (void)s; return 2; }\n"
+                "  catch (const yart::hip::Error&) {}\n"
+                "  return yart_hip_abi_version() == YART_HIP_ABI_VERSION ? 0 : 1; }\n")
+    exe = os.path.join(tmp_path, "m")
+    lib_dir = os.path.join(ROOT, "yart_amd")
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + lib_dir, "-lyart_hip",
+                    "-Wl,-rpath," + lib_dir, "-lpthread"], check=True)
+    assert subprocess.run([exe]).returncode == 0

@@ -173,8 +173,8 @@ void yart_hip_scene_destroy(YartScene* scene);
  * transmission / ior / anisotropy / clearcoat / volume / emissive_strength extensions (gltf.cpp:62-176),
  * gamma-2 re-encoded textures (core/texture.hpp:62-92), the primitives of each mesh merged (gltf.cpp:178-270),
  * the T*R*S node tree and one AreaLight per emissive triangle with per-node light indices (gltf.cpp:272-317).
- * Embedded PNG and baseline JPEG images are decoded (to the bytes the reference's stb_image call yields);
- * progressive JPEG images and sparse accessors are refused (YART_E_IO, see yart_hip_last_error). opts may be NULL (asset only). env_hdr_path: octahedral-mapped Radiance .hdr wrapped
+ * Embedded PNG and JPEG (baseline / progressive Huffman) images are decoded to the bytes the reference's
+ * stb_image call yields; arithmetic-coded / CMYK JPEG images and sparse accessors are refused (YART_E_IO, see yart_hip_last_error). opts may be NULL (asset only). env_hdr_path: octahedral-mapped Radiance .hdr wrapped
  * in ImageInfiniteLight(env_radius, texture) (core/texture.cpp:5-20); uniform_env != 0 adds
  * UniformInfiniteLight(env_radius, uniform_emission). env_radius <= 0 means 100 (main.cpp:82). */
 typedef struct YartImportOptions {

@@ -280,100 +280,123 @@ class _BitWriter:
             self.put((1 << (8 - self.n)) - 1, 8 - self.n)      # pad with 1-bits
 
 
-def jpeg_encode(pixels, sampling=((1, 1), (1, 1), (1, 1)), quant=(8, 12), restart=0, interleaved=True, jfif=True,
-                adobe_transform=None, component_ids=(1, 2, 3), fill_bytes=False):
-    """Baseline sequential JPEG (T.81) of an (h, w, 1|3) uint8 array whose channels are stored as given (Y / Cb / Cr,
-    or R / G / B for the RGB-id cases): the caller decides what the samples mean, the decoders under test must agree
-    on the result. Flat quantisation tables (luma, chroma steps), fixed-length Huffman codes (12 DC categories of
-    4 bits, the 162 AC symbols of 8 bits): any valid table is as good as another for a decoder test.
-    sampling: (h, v) per component; restart: MCUs per restart interval; interleaved=False writes one scan per
-    component."""
+def _jpeg_coefficients(pixels, sampling, quant):
+    """Quantised DCT coefficients in zigzag order: per component an array (blocks_y, blocks_x, 64) over the
+    MCU-padded grid, plus the frame geometry."""
     px = np.asarray(pixels, np.float64)
     H, W, nc = px.shape
     samp = list(sampling)[:nc]
     hmax = max(h for h, v in samp); vmax = max(v for h, v in samp)
     mcu_x = -(-W // (8 * hmax)); mcu_y = -(-H // (8 * vmax))
-    # component planes, subsampled by box averaging and padded by edge replication to the MCU grid
-    planes = []
+    k = np.arange(8)
+    D = np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16) * np.where(k[:, None] == 0, np.sqrt(1 / 8), np.sqrt(2 / 8))
+    coefs = []
     for c, (h, v) in enumerate(samp):
         fx, fy = hmax // h, vmax // v
         cw, ch = -(-W * h // hmax), -(-H * v // vmax)
         full = np.pad(px[..., c], ((0, ch * fy - H), (0, cw * fx - W)), mode="edge")
-        sub = full.reshape(ch, fy, cw, fx).mean(axis=(1, 3))
-        planes.append(np.pad(sub, ((0, mcu_y * v * 8 - ch), (0, mcu_x * h * 8 - cw)), mode="edge"))
-    k = np.arange(8)
-    D = np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16) * np.where(k[:, None] == 0, np.sqrt(1 / 8), np.sqrt(2 / 8))
-    dc_syms = list(range(12))
-    ac_syms = [0x00, 0xF0] + [(r << 4) | s for r in range(16) for s in range(1, 11)]
-    dc_code = {s: (i, 4) for i, s in enumerate(dc_syms)}
-    ac_code = {s: (i, 8) for i, s in enumerate(ac_syms)}
+        sub = full.reshape(ch, fy, cw, fx).mean(axis=(1, 3))          # box-filtered subsampling
+        plane = np.pad(sub, ((0, mcu_y * v * 8 - ch), (0, mcu_x * h * 8 - cw)), mode="edge")
+        by, bx = plane.shape[0] // 8, plane.shape[1] // 8
+        blocks = plane.reshape(by, 8, bx, 8).transpose(0, 2, 1, 3) - 128.0
+        q = quant[0 if c == 0 else 1]
+        co = np.rint(np.einsum("ij,yxjk,lk->yxil", D, blocks, D) / q).astype(np.int64).reshape(by, bx, 64)
+        coefs.append(np.clip(co[..., _ZIGZAG], -1023, 1023))
+    geo = dict(H=H, W=W, nc=nc, samp=samp, hmax=hmax, vmax=vmax, mcu_x=mcu_x, mcu_y=mcu_y)
+    return coefs, geo
 
-    def seg(marker, body):
-        return bytes((0xFF, marker)) + struct.pack(">H", len(body) + 2) + body
+
+_DC_SYMS = list(range(12))
+_AC_SYMS = [0x00, 0xF0] + [(r << 4) | s for r in range(16) for s in range(1, 11)] + [r << 4 for r in range(1, 15)]
+_DC_CODE = {s: (i, 4) for i, s in enumerate(_DC_SYMS)}            # 12 codes of 4 bits
+_AC_CODE = {s: (i, 8) for i, s in enumerate(_AC_SYMS)}            # 176 codes of 8 bits (EOB0..14, ZRL, run/size)
+
+
+def _seg(marker, body):
+    return bytes((0xFF, marker)) + struct.pack(">H", len(body) + 2) + body
+
+
+def _jpeg_header(geo, quant, sof, restart, jfif, adobe_transform, component_ids):
     out = bytearray(b"\xFF\xD8")
     if jfif:
-        out += seg(0xE0, b"JFIF\0\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+        out += _seg(0xE0, b"JFIF\0\x01\x01\x00\x00\x01\x00\x01\x00\x00")
     if adobe_transform is not None:
-        out += seg(0xEE, b"Adobe\0" + bytes((100, 0, 0, 0, 0, adobe_transform)))
-    out += seg(0xFE, b"test asset")
+        out += _seg(0xEE, b"Adobe\0" + bytes((100, 0, 0, 0, 0, adobe_transform)))
+    out += _seg(0xFE, b"test asset")
     for t, q in enumerate(quant):
-        out += seg(0xDB, bytes((t,)) + bytes([q] * 64))
-    out += seg(0xC0, struct.pack(">BHHB", 8, H, W, nc) +
-               b"".join(bytes((component_ids[c], (samp[c][0] << 4) | samp[c][1], 0 if c == 0 else 1)) for c in range(nc)))
-    out += seg(0xC4, bytes((0x00,)) + bytes([0, 0, 0, 12] + [0] * 12) + bytes(dc_syms))
-    out += seg(0xC4, bytes((0x10,)) + bytes([0] * 7 + [162] + [0] * 8) + bytes(ac_syms))
+        out += _seg(0xDB, bytes((t,)) + bytes([q] * 64))
+    nc, samp = geo["nc"], geo["samp"]
+    out += _seg(sof, struct.pack(">BHHB", 8, geo["H"], geo["W"], nc) +
+                b"".join(bytes((component_ids[c], (samp[c][0] << 4) | samp[c][1], 0 if c == 0 else 1)) for c in range(nc)))
+    out += _seg(0xC4, bytes((0x00,)) + bytes([0, 0, 0, len(_DC_SYMS)] + [0] * 12) + bytes(_DC_SYMS))
+    out += _seg(0xC4, bytes((0x10,)) + bytes([0] * 7 + [len(_AC_SYMS)] + [0] * 8) + bytes(_AC_SYMS))
     if restart:
-        out += seg(0xDD, struct.pack(">H", restart))
+        out += _seg(0xDD, struct.pack(">H", restart))
+    return out
 
-    def category(v):
-        return int(abs(v)).bit_length()
 
-    def encode_block(bw, plane, bx, by, q, pred):
-        blk = plane[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] - 128.0
-        coef = np.rint(D @ blk @ D.T / q).astype(np.int64).reshape(64)
-        zz = [int(coef[i]) for i in _ZIGZAG]
-        diff = zz[0] - pred
-        s = category(diff)
-        bw.put(*dc_code[s])
+def _scan_units(geo, comps):
+    """Blocks (component, bx, by) per MCU of a scan: the component's own block grid for a single-component scan,
+    interleaved MCUs otherwise."""
+    samp, hmax, vmax, W, H = geo["samp"], geo["hmax"], geo["vmax"], geo["W"], geo["H"]
+    if len(comps) == 1:
+        c = comps[0]
+        h, v = samp[c]
+        bw = -(-(-(-W * h // hmax)) // 8); bh = -(-(-(-H * v // vmax)) // 8)
+        return [[(c, i, j)] for j in range(bh) for i in range(bw)]
+    return [[(c, i * samp[c][0] + x, j * samp[c][1] + y) for c in comps for y in range(samp[c][1]) for x in range(samp[c][0])]
+            for j in range(geo["mcu_y"]) for i in range(geo["mcu_x"])]
+
+
+def _put_value(bw, v, s):
+    bw.put(v if v >= 0 else v + (1 << s) - 1, s)
+
+
+def jpeg_encode(pixels, sampling=((1, 1), (1, 1), (1, 1)), quant=(8, 12), restart=0, interleaved=True, jfif=True,
+                adobe_transform=None, component_ids=(1, 2, 3), fill_bytes=False):
+    """Baseline sequential JPEG (T.81) of an (h, w, 1|3) uint8 array whose channels are stored as given (Y / Cb / Cr,
+    or R / G / B for the RGB-id cases): the caller decides what the samples mean, the decoders under test must agree
+    on the result. Flat quantisation tables (luma, chroma steps), fixed-length Huffman codes (12 DC categories of
+    4 bits, 176 AC symbols of 8 bits): any valid table is as good as another for a decoder test.
+    sampling: (h, v) per component; restart: MCUs per restart interval; interleaved=False writes one scan per
+    component."""
+    coefs, geo = _jpeg_coefficients(pixels, sampling, quant)
+    nc = geo["nc"]
+    out = _jpeg_header(geo, quant, 0xC0, restart, jfif, adobe_transform, component_ids)
+
+    def encode_block(bw, zz, pred):
+        diff = int(zz[0]) - pred
+        s = int(abs(diff)).bit_length()
+        bw.put(*_DC_CODE[s])
         if s:
-            bw.put(diff if diff >= 0 else diff + (1 << s) - 1, s)
+            _put_value(bw, diff, s)
         run = 0
         last = max((i for i in range(1, 64) if zz[i]), default=0)
         for i in range(1, last + 1):
-            if zz[i] == 0:
+            v = int(zz[i])
+            if v == 0:
                 run += 1
                 continue
             while run > 15:
-                bw.put(*ac_code[0xF0]); run -= 16
-            v = max(-1023, min(1023, zz[i]))
-            s = category(v)
-            bw.put(*ac_code[(run << 4) | s])
-            bw.put(v if v >= 0 else v + (1 << s) - 1, s)
+                bw.put(*_AC_CODE[0xF0]); run -= 16
+            s = abs(v).bit_length()
+            bw.put(*_AC_CODE[(run << 4) | s])
+            _put_value(bw, v, s)
             run = 0
         if last < 63:
-            bw.put(*ac_code[0x00])
-        return zz[0]
+            bw.put(*_AC_CODE[0x00])
+        return int(zz[0])
 
     def scan(comps):
         nonlocal out
-        out += seg(0xDA, bytes((len(comps),)) + b"".join(bytes((component_ids[c], 0x00)) for c in comps) + bytes((0, 63, 0)))
+        out += _seg(0xDA, bytes((len(comps),)) + b"".join(bytes((component_ids[c], 0x00)) for c in comps) + bytes((0, 63, 0)))
         bw = _BitWriter()
         pred = {c: 0 for c in comps}
-        units = []
-        if len(comps) == 1:
-            c = comps[0]
-            h, v = samp[c]
-            bwid = -(-(-(-W * h // hmax)) // 8); bhei = -(-(-(-H * v // vmax)) // 8)
-            units = [[(c, i, j)] for j in range(bhei) for i in range(bwid)]
-        else:
-            for j in range(mcu_y):
-                for i in range(mcu_x):
-                    units.append([(c, i * samp[c][0] + x, j * samp[c][1] + y) for c in comps
-                                  for y in range(samp[c][1]) for x in range(samp[c][0])])
+        units = _scan_units(geo, comps)
         rst = 0
         for n, unit in enumerate(units):
             for c, bx, by in unit:
-                pred[c] = encode_block(bw, planes[c], bx, by, quant[0 if c == 0 else 1], pred[c])
+                pred[c] = encode_block(bw, coefs[c][by, bx], pred[c])
             if restart and (n + 1) % restart == 0 and n + 1 < len(units):
                 bw.flush()
                 out += bw.out + (b"\xFF" if fill_bytes else b"") + bytes((0xFF, 0xD0 + rst % 8))
@@ -386,5 +409,120 @@ def jpeg_encode(pixels, sampling=((1, 1), (1, 1), (1, 1)), quant=(8, 12), restar
     else:
         for c in range(nc):
             scan([c])
+    out += b"\xFF\xD9"
+    return bytes(out)
+
+
+def jpeg_encode_progressive(pixels, sampling=((1, 1), (1, 1), (1, 1)), quant=(8, 12), restart=0, script=None,
+                            jfif=True, component_ids=(1, 2, 3)):
+    """Progressive JPEG (T.81 Annex G: spectral selection + successive approximation) with the same tables as
+    jpeg_encode. script: list of scans — ("dc", ah, al) over all components interleaved, or ("ac", component, ss, se,
+    ah, al); the default refines every coefficient down to bit 0, so the decoded image equals the baseline file's."""
+    coefs, geo = _jpeg_coefficients(pixels, sampling, quant)
+    nc = geo["nc"]
+    if script is None:
+        script = [("dc", 0, 1), ("ac", 0, 1, 5, 0, 2)]
+        script += [("ac", c, 1, 63, 0, 1) for c in range(1, nc)]
+        script += [("ac", 0, 6, 63, 0, 2), ("ac", 0, 1, 63, 2, 1), ("dc", 1, 0)]
+        script += [("ac", c, 1, 63, 1, 0) for c in range(nc)]
+    out = _jpeg_header(geo, quant, 0xC2, restart, jfif, None, component_ids)
+
+    for sc in script:
+        if sc[0] == "dc":
+            _, ah, al = sc
+            comps, ss, se = list(range(nc)), 0, 0
+        else:
+            _, c, ss, se, ah, al = sc
+            comps = [c]
+        out += _seg(0xDA, bytes((len(comps),)) + b"".join(bytes((component_ids[c], 0x00)) for c in comps) +
+                    bytes((ss, se, (ah << 4) | al)))
+        bw = _BitWriter()
+        state = dict(pred={c: 0 for c in comps}, eobrun=0, pending=[])      # pending: buffered correction bits
+
+        def flush_eobrun():
+            if state["eobrun"]:
+                n = state["eobrun"].bit_length() - 1
+                bw.put(*_AC_CODE[n << 4])
+                if n:
+                    bw.put(state["eobrun"] & ((1 << n) - 1), n)
+                state["eobrun"] = 0
+            for b in state["pending"]:
+                bw.put(b, 1)
+            state["pending"] = []
+
+        def block(c, zz):
+            if ss == 0:
+                if ah == 0:
+                    v = int(zz[0]) >> al                                   # point transform: arithmetic shift
+                    diff = v - state["pred"][c]; state["pred"][c] = v
+                    s = abs(diff).bit_length()
+                    bw.put(*_DC_CODE[s])
+                    if s:
+                        _put_value(bw, diff, s)
+                else:
+                    bw.put((int(zz[0]) >> al) & 1, 1)
+                return
+            t = [abs(int(zz[k])) >> al for k in range(64)]                 # point transform: magnitude shift
+            if ah == 0:
+                run = 0
+                for k in range(ss, se + 1):
+                    if t[k] == 0:
+                        run += 1
+                        continue
+                    flush_eobrun()
+                    while run > 15:
+                        bw.put(*_AC_CODE[0xF0]); run -= 16
+                    s = t[k].bit_length()
+                    bw.put(*_AC_CODE[(run << 4) | s])
+                    _put_value(bw, t[k] if zz[k] > 0 else -t[k], s)
+                    run = 0
+                if run > 0:
+                    state["eobrun"] += 1
+                    if state["eobrun"] == 0x7FFF:
+                        flush_eobrun()
+                return
+            eob = max((k for k in range(ss, se + 1) if t[k] == 1), default=-1)   # last newly non-zero coefficient
+            run = 0
+            bits = []
+            for k in range(ss, se + 1):
+                if t[k] == 0:
+                    run += 1
+                    continue
+                while run > 15 and k <= eob:
+                    flush_eobrun()
+                    bw.put(*_AC_CODE[0xF0]); run -= 16
+                    for b in bits:
+                        bw.put(b, 1)
+                    bits = []
+                if t[k] > 1:
+                    bits.append(t[k] & 1)                                  # correction bit of an already non-zero one
+                    continue
+                flush_eobrun()
+                bw.put(*_AC_CODE[(run << 4) | 1])
+                bw.put(1 if zz[k] > 0 else 0, 1)
+                for b in bits:
+                    bw.put(b, 1)
+                bits = []
+                run = 0
+            if run > 0 or bits:
+                state["eobrun"] += 1
+                state["pending"] += bits
+                if state["eobrun"] == 0x7FFF or len(state["pending"]) > 900:
+                    flush_eobrun()
+
+        units = _scan_units(geo, comps)
+        rst = 0
+        for n, unit in enumerate(units):
+            for c, bx, by in unit:
+                block(c, coefs[c][by, bx])
+            if restart and (n + 1) % restart == 0 and n + 1 < len(units):
+                flush_eobrun()
+                bw.flush()
+                out += bw.out + bytes((0xFF, 0xD0 + rst % 8))
+                bw = _BitWriter(); rst += 1
+                state["pred"] = {c: 0 for c in comps}
+        flush_eobrun()
+        bw.flush()
+        out += bw.out
     out += b"\xFF\xD9"
     return bytes(out)

@@ -6,10 +6,11 @@ Runs only where /root/reference is mounted (the build container):
 Inputs (written by tests/gltf_assets.py, all small):
     png_<case>.png          PNG files covering colour types 0/2/3/4/6, bit depths 1-16, every scanline filter, Adam7
                             interlace, tRNS keys and palette alpha, split IDAT
-    jpg_<case>.jpg          baseline JPEG files from two encoders (stb_image_write via `yart_ref writejpg`, and
+    jpg_<case>.jpg          baseline and progressive JPEG files from two encoders (stb_image_write via `yart_ref writejpg`, and
                             tests/gltf_assets.jpeg_encode): 4:4:4 / 4:2:0 / 4:2:2 / 4:4:0 / 4:1:1 / odd factors, grey, restart
                             intervals with fill bytes, one scan per component, RGB component ids, Adobe / JFIF signalling,
-                            1- and 2-pixel-wide images, saturated chroma
+                            1- and 2-pixel-wide images, saturated chroma; progressive files (spectral selection, successive
+                            approximation, EOB runs, restart intervals, partially refined)
     env_rle.hdr / env_flat.hdr / env_tiny.hdr   Radiance files (RLE scanlines, flat, width < 8)
     xform.txt               node T / R / S rows with parent links
     gallery.glb             a small scene using every material extension the importer maps, merged primitives, strided /
@@ -113,6 +114,18 @@ def jpeg_cases(tmp_png):
         "w2_422": e(img[:9, :2], sampling=((2, 1), (1, 1), (1, 1))),
         "sat": e(np.where((xx // 6 + yy // 5)[..., None] % 2 == 0, np.array([250, 10, 250]), np.array([5, 250, 8])).astype(np.uint8),
                  sampling=((2, 2), (1, 1), (1, 1)), quant=(2, 2)),      # saturated chroma: exercises the clamps
+    })
+    pe = ga.jpeg_encode_progressive
+    cases.update({
+        "prog_444": pe(img),
+        "prog_420": pe(img, sampling=((2, 2), (1, 1), (1, 1)), quant=(3, 4)),
+        "prog_420_rst": pe(img, sampling=((2, 2), (1, 1), (1, 1)), restart=4),
+        "prog_422_partial": pe(img, sampling=((2, 1), (1, 1), (1, 1)),      # stops before the last refinement passes
+                               script=[("dc", 0, 2), ("ac", 0, 1, 9, 0, 1), ("ac", 1, 1, 63, 0, 2), ("ac", 2, 1, 20, 0, 0),
+                                       ("dc", 2, 1), ("ac", 0, 10, 63, 0, 3), ("ac", 0, 10, 63, 3, 2)]),
+        "prog_gray": pe(img[..., :1]),
+        "prog_w2": pe(img[:11, :2], sampling=((2, 2), (1, 1), (1, 1))),
+        "prog_flat": pe(np.full((40, 40, 3), 77, np.uint8), sampling=((2, 2), (1, 1), (1, 1))),   # long EOB runs
     })
     os.remove(tmp_png)
     return cases

@@ -233,12 +233,12 @@ def _expect_error(api, path, fragment, tmp_path):
 
 
 def test_unsupported_or_broken_assets_fail_loudly(api, tmp_path):
-    # progressive JPEG (SOF2): refused, not approximated
+    # arithmetic-coded JPEG (SOF9): refused, not approximated
     b = ga.GltfBuilder()
-    jpeg = ga.jpeg_encode(np.full((8, 8, 3), 128, np.uint8)).replace(b"\xFF\xC0", b"\xFF\xC2", 1)
+    jpeg = ga.jpeg_encode(np.full((8, 8, 3), 128, np.uint8)).replace(b"\xFF\xC0", b"\xFF\xC9", 1)
     b.node(_triangle_mesh(b, b.material(pbrMetallicRoughness={"baseColorTexture": {"index": b.texture(b.image(jpeg, mime="image/jpeg"))}})), root=True)
     p = os.path.join(tmp_path, "jpeg.glb"); b.write_glb(p)
-    _expect_error(api, p, "progressive", tmp_path)
+    _expect_error(api, p, "arithmetic", tmp_path)
     # truncated JPEG
     b = ga.GltfBuilder()
     jpeg = ga.jpeg_encode(np.full((16, 16, 3), 99, np.uint8))[:200]

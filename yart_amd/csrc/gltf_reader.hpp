@@ -23,9 +23,9 @@
 // samplers (wrap is always repeat), vertex colours, skins, animations, morph targets.
 // Node `matrix` properties are decomposed to T / R / S first (fastgltf's DecomposeNodeMatrices
 // option); that decomposition is restated from the glTF specification, so matrix-valued nodes may
-// differ from the reference in the last bits of the node transform. Embedded PNG and baseline JPEG
-// images are decoded to the reference's bytes (image_decode.hpp); progressive JPEG and sparse accessors
-// are refused with an error.
+// differ from the reference in the last bits of the node transform. Embedded PNG and JPEG
+// images are decoded to the reference's bytes (image_decode.hpp); arithmetic-coded / CMYK JPEG and sparse
+// accessors are refused with an error.
 #pragma once
 #include <algorithm>
 #include <cctype>

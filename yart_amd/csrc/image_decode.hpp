@@ -7,8 +7,8 @@
 // high byte, 1/2/4-bit grey is scaled to 0..255, grey / RGB gain alpha 255, a tRNS colour key
 // gives alpha 0, RGBE mantissas are scaled by 2^(e-136) with alpha 1. PNG is lossless, so the
 // bytes equal the reference's (pinned by tests/golden/gltf/*.tex against oracle/_ref `texture`).
-// Baseline JPEG is decoded with the integer arithmetic stb_image documents for the parts the standard
-// leaves open (see decodeJpeg); progressive / arithmetic / CMYK files are refused with an error.
+// Baseline and progressive Huffman JPEG are decoded with the integer arithmetic stb_image documents for the
+// parts the standard leaves open (see decodeJpeg); arithmetic-coded / CMYK files are refused with an error.
 #pragma once
 #include <zlib.h>
 
@@ -192,8 +192,10 @@ inline Image8 decodePng(const uint8_t* data, size_t len) {
 //   * colour: 20-bit fixed point, the Cb term of green masked to its high 16 bits; a 3-component frame is taken
 //     as RGB when its component ids are 'R','G','B' or when an Adobe APP14 marker says transform 0 and there
 //     is no JFIF marker.
+// Progressive frames (SOF2: spectral selection and successive approximation, T.81 Annex G) accumulate their
+// coefficients over the scans and are dequantised (16-bit wrap-around as in stb_image) and transformed at the end.
 // Pinned against the reference's loader on files from two independent encoders (tests/golden/gltf/jpg_*).
-// Progressive (SOF2), arithmetic-coded, lossless, 12-bit and 4-component (CMYK / YCCK) files are refused.
+// Arithmetic-coded, lossless, hierarchical, 12-bit and 4-component (CMYK / YCCK) files are refused.
 namespace detail {
 struct JpegHuff {
   uint8_t bits[17] = {0};          // number of codes of each length 1..16
@@ -304,10 +306,15 @@ static const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18
 inline Image8 decodeJpeg(const uint8_t* data, size_t len) {
   using namespace detail;
   if (!isJpeg(data, len)) throw std::runtime_error("jpeg: no SOI marker");
-  struct Comp { int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dcPred = 0; uint32_t x = 0, y = 0, w2 = 0, h2 = 0; std::vector<uint8_t> plane; };
+  struct Comp {
+    int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dcPred = 0;
+    uint32_t x = 0, y = 0, w2 = 0, h2 = 0;
+    std::vector<uint8_t> plane;
+    std::vector<int16_t> coef;       // progressive: 64 coefficients per block, (w2 / 8) x (h2 / 8) blocks
+  };
   Comp comp[3];
   int nComp = 0, hMax = 1, vMax = 1, restartInterval = 0, adobe = -1, rgbIds = 0;
-  bool jfif = false, haveFrame = false, sawScan = false;
+  bool jfif = false, haveFrame = false, sawScan = false, progressive = false;
   uint32_t W = 0, H = 0, mcuX = 0, mcuY = 0;
   uint16_t dequant[4][64] = {};
   JpegHuff hdc[4], hac[4];
@@ -326,7 +333,8 @@ inline Image8 decodeJpeg(const uint8_t* data, size_t len) {
     pending = -1;
     if (m == 0xD9) break;                                              // EOI
     if (m >= 0xD0 && m <= 0xD7) continue;                              // stray RSTn between segments
-    if (m == 0xC0 || m == 0xC1) {                                      // SOF0 / SOF1
+    if (m == 0xC0 || m == 0xC1 || m == 0xC2) {                         // SOF0 / SOF1 / SOF2
+      progressive = m == 0xC2;
       if (haveFrame) throw std::runtime_error("jpeg: more than one frame");
       const int Lf = u16();
       if (u8() != 8) throw std::runtime_error("jpeg: only 8-bit samples are supported");
@@ -351,10 +359,9 @@ inline Image8 decodeJpeg(const uint8_t* data, size_t len) {
         c.x = (W * uint32_t(c.h) + uint32_t(hMax) - 1) / uint32_t(hMax); c.y = (H * uint32_t(c.v) + uint32_t(vMax) - 1) / uint32_t(vMax);
         c.w2 = mcuX * uint32_t(c.h) * 8; c.h2 = mcuY * uint32_t(c.v) * 8;
         c.plane.assign(size_t(c.w2) * c.h2, 0);
+        if (progressive) c.coef.assign(size_t(c.w2) * c.h2, 0);
       }
       haveFrame = true;
-    } else if (m == 0xC2) {
-      throw std::runtime_error("jpeg: progressive files are not supported (re-encode as baseline JPEG or PNG)");
     } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
       throw std::runtime_error("jpeg: lossless / hierarchical / arithmetic-coded files are not supported");
     } else if (m == 0xC4) {                                            // DHT
@@ -399,12 +406,78 @@ inline Image8 decodeJpeg(const uint8_t* data, size_t len) {
         if (comp[which].hd > 3 || comp[which].ha > 3) throw std::runtime_error("jpeg: bad Huffman table index");
         order[i] = which;
       }
-      const int ss = u8(); (void)u8(); const int a = u8();
-      if (ss != 0 || a != 0) throw std::runtime_error("jpeg: bad SOS parameters for a sequential frame");
+      const int ss = u8(), se = u8(), a = u8(), ah = a >> 4, al = a & 15;
+      if (!progressive) { if (ss != 0 || a != 0) throw std::runtime_error("jpeg: bad SOS parameters for a sequential frame"); }
+      else {
+        if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13) throw std::runtime_error("jpeg: bad SOS parameters");
+        if (ss == 0 && se != 0) throw std::runtime_error("jpeg: a progressive scan cannot mix DC and AC coefficients");
+        if (ss != 0 && ns != 1) throw std::runtime_error("jpeg: progressive AC scans hold one component");
+      }
       JpegBits br{data + pos, data + len};
       int todo = restartInterval ? restartInterval : 0x7fffffff;
+      int eobRun = 0;
       for (int i = 0; i < nComp; i++) comp[i].dcPred = 0;
+      // progressive scans (T.81 G.1.2): the block's 64 coefficients live in c.coef across scans
+      auto progBlock = [&](Comp& c, size_t bx, size_t by) {
+        int16_t* d = c.coef.data() + 64 * (bx + by * size_t(c.w2 / 8));
+        if (ss == 0) {                                                 // DC: first pass or one more bit
+          if (ah == 0) {
+            const JpegHuff& dc = hdc[c.hd];
+            if (!dc.defined) throw std::runtime_error("jpeg: scan uses an undefined Huffman table");
+            const int t = jpegDecodeSymbol(br, dc);
+            if (t > 15) throw std::runtime_error("jpeg: bad DC category");
+            c.dcPred += jpegExtend(br.get(t), t);
+            std::memset(d, 0, 64 * sizeof(int16_t));
+            d[0] = int16_t(c.dcPred * (1 << al));
+          } else if (br.bit()) d[0] = int16_t(d[0] + int16_t(1 << al));
+          return;
+        }
+        const JpegHuff& ac = hac[c.ha];
+        if (!ac.defined) throw std::runtime_error("jpeg: scan uses an undefined Huffman table");
+        if (ah == 0) {                                                 // AC first pass
+          if (eobRun) { eobRun--; return; }
+          int k = ss;
+          do {
+            const int rs = jpegDecodeSymbol(br, ac), sz = rs & 15, r = rs >> 4;
+            if (sz == 0) {
+              if (r < 15) { eobRun = 1 << r; if (r) eobRun += br.get(r); eobRun--; break; }
+              k += 16;
+            } else {
+              k += r;
+              if (k > 63) throw std::runtime_error("jpeg: AC run past the end of the block");
+              d[kZigzag[k++]] = int16_t(jpegExtend(br.get(sz), sz) * (1 << al));
+            }
+          } while (k <= se);
+          return;
+        }
+        const int16_t bit = int16_t(1 << al);                          // AC refinement
+        auto refine = [&](int16_t& p) {
+          if (br.bit() && (p & bit) == 0) p = int16_t(p > 0 ? p + bit : p - bit);
+        };
+        if (eobRun) {
+          eobRun--;
+          for (int k = ss; k <= se; k++) { int16_t& p = d[kZigzag[k]]; if (p != 0) refine(p); }
+          return;
+        }
+        int k = ss;
+        do {
+          const int rs = jpegDecodeSymbol(br, ac);
+          int sz = rs & 15, r = rs >> 4;
+          if (sz == 0) {
+            if (r < 15) { eobRun = (1 << r) - 1; if (r) eobRun += br.get(r); r = 64; }
+          } else {
+            if (sz != 1) throw std::runtime_error("jpeg: bad refinement code");
+            sz = br.bit() ? bit : -bit;
+          }
+          while (k <= se) {
+            int16_t& p = d[kZigzag[k++]];
+            if (p != 0) refine(p);
+            else { if (r == 0) { p = int16_t(sz); break; } r--; }
+          }
+        } while (k <= se);
+      };
       auto block = [&](Comp& c, size_t bx, size_t by) {
+        if (progressive) { progBlock(c, bx, by); return; }
         const JpegHuff& dc = hdc[c.hd]; const JpegHuff& ac = hac[c.ha];
         if (!dc.defined || !ac.defined) throw std::runtime_error("jpeg: scan uses an undefined Huffman table");
         const uint16_t* dq = dequant[c.tq];
@@ -429,6 +502,7 @@ inline Image8 decodeJpeg(const uint8_t* data, size_t len) {
         if (br.marker < 0xD0 || br.marker > 0xD7) throw std::runtime_error("jpeg: restart marker expected");
         br.reset();
         for (int i = 0; i < nComp; i++) comp[i].dcPred = 0;
+        eobRun = 0;
         todo = restartInterval;
       };
       if (ns == 1) {                                                   // non-interleaved: the component's own block grid
@@ -466,6 +540,17 @@ inline Image8 decodeJpeg(const uint8_t* data, size_t len) {
     }
   }
   if (!haveFrame || !sawScan) throw std::runtime_error("jpeg: no image data");
+  if (progressive)
+    for (int i = 0; i < nComp; i++) {
+      Comp& c = comp[i];
+      const size_t bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+      for (size_t by = 0; by < bh; by++)
+        for (size_t bx = 0; bx < bw; bx++) {
+          int16_t* d = c.coef.data() + 64 * (bx + by * size_t(c.w2 / 8));
+          for (int k = 0; k < 64; k++) d[k] = int16_t(d[k] * dequant[c.tq][k]);
+          jpegIdct(c.plane.data() + size_t(c.w2) * by * 8 + bx * 8, c.w2, d);
+        }
+    }
 
   Image8 img;
   img.width = W; img.height = H;

@@ -106,8 +106,8 @@ typedef struct YartCameraDesc {
 
 /* TileRenderer knobs (src/cpu/tile-renderer.hpp:27-32), Renderer::backgroundColor
  * (src/core/renderer.hpp:52), RayIntegrator::m_maxDepth (src/cpu/ray-integrator.hpp:14).
- * rank/world_size: this process renders the 64x64 tiles t with t % world_size == rank
- * (tiles numbered in Morton order) and leaves the other pixels 0. */
+ * rank/world_size: this process renders the pixel blocks b with b % world_size == rank (blocks of shard_tile,
+ * by default tile_size, pixels numbered in Morton order) and leaves the other pixels 0. */
 typedef struct YartRenderParams {
   uint32_t samples, first_wave_samples, max_wave_samples, tile_size, max_depth;
   float background[3];
@@ -123,7 +123,10 @@ typedef struct YartRenderParams {
    * (cpu/integrator.cpp:17-18: GMoNEstimator(samples, 15) as shipped, MeanEstimator in the commented line);
    * MoN and GMoNb take the same (samples, 15). 0 keeps the shipped behaviour. */
   uint32_t estimator;        /* YART_ESTIMATOR_* */
-  uint32_t reserved[1];
+  /* Edge of the square pixel blocks dealt to the ranks (Morton order, round-robin); 0 = tile_size, the
+   * reference's unit of parallel work. Which process renders a pixel does not change it (the sampler only
+   * knows tile_size), so a smaller block only evens out the load between GPUs. */
+  uint32_t shard_tile;
 } YartRenderParams;
 #define YART_ESTIMATOR_GMON 0u      /* core/estimator.hpp:148-198 */
 #define YART_ESTIMATOR_MEAN 1u      /* :29-46 */

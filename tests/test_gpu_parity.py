@@ -140,6 +140,13 @@ def test_tile_sharding_partitions_the_frame(api):
     for r in range(2):
         assert np.array_equal(parts[r][..., 3] == 1.0, yd.pixel_mask(128, 128, 64, r, 2))
     assert np.array_equal((parts[0] + parts[1]).view(np.uint32), full.view(np.uint32))
+    # finer sharding blocks (shard_tile) deal the same pixels differently; the sampler still only knows tile_size
+    for shard, world in ((16, 3), (8, 5)):
+        q = dict(p, shard_tile=shard)
+        parts = [scene.render(q, rank=r, world_size=world)[0] for r in range(world)]
+        for r in range(world):
+            assert np.array_equal(parts[r][..., 3] == 1.0, yd.pixel_mask(128, 128, shard, r, world))
+        assert np.array_equal(sum(parts).view(np.uint32), full.view(np.uint32))
     scene.close()
 
 

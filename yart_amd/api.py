@@ -97,7 +97,7 @@ class RenderParams(C.Structure):
                 ("max_wave_samples", C.c_uint32), ("tile_size", C.c_uint32), ("max_depth", C.c_uint32),
                 ("background", C.c_float * 3), ("rank", C.c_uint32), ("world_size", C.c_uint32),
                 ("flags", C.c_uint32), ("start_sample", C.c_uint32), ("stop_sample", C.c_uint32),
-                ("estimator", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("estimator", C.c_uint32), ("shard_tile", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -220,6 +220,7 @@ def make_params(p: dict, rank=0, world_size=1, flags=0) -> RenderParams:
     r.rank, r.world_size, r.flags = int(rank), int(world_size), int(flags)
     r.start_sample, r.stop_sample = int(p.get("start_sample", 0)), int(p.get("stop_sample", 0))
     r.estimator = int(p.get("estimator", ESTIMATOR_GMON))
+    r.shard_tile = int(p.get("shard_tile", 0))
     return r
 
 

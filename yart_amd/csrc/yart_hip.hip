@@ -359,6 +359,7 @@ void validate(const YartCameraDesc* cam, const YartRenderParams* p) {
           "image size must be in [1, 65535]");
   require(p->samples > 0 && p->first_wave_samples > 0 && p->max_wave_samples > 0, "sample counts must be > 0");
   require(p->tile_size > 0 && p->tile_size <= 4096, "tile_size out of range");
+  require(p->shard_tile <= 4096, "shard_tile out of range");
   require(p->world_size > 0 && p->rank < p->world_size, "rank / world_size");
   require(p->max_depth > 0, "max_depth must be > 0");
   require(p->start_sample < p->samples && (p->stop_sample == 0 || (p->stop_sample > p->start_sample && p->stop_sample <= p->samples)),
@@ -415,7 +416,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const CameraDev cam = makeCamera(camDesc);
   const RenderConst rc = makeRenderConst(p);
   const bool mega = (p.flags & YART_FLAG_MEGAKERNEL) != 0;
-  buildPixelList(s, W, H, p.tile_size, p.rank, p.world_size);
+  buildPixelList(s, W, H, p.shard_tile ? p.shard_tile : p.tile_size, p.rank, p.world_size);
   const uint32_t nPix = uint32_t(s.pixelsHost.size());
 
   const uint64_t startSample = p.start_sample, stopSample = p.stop_sample ? p.stop_sample : p.samples;

@@ -1,0 +1,108 @@
+// hip-renderer.hpp — the adapter a yart maintainer drops into the reference tree (e.g. as src/hip/hip-renderer.hpp):
+// a yart::Renderer (src/core/renderer.hpp:17-104) that renders on libyart_hip.so instead of the CPU tile threads of
+// yart::cpu::TileRenderer (src/cpu/tile-renderer.hpp:22-310). Same public knobs and callbacks; the tonemapper stays
+// the reference's own host object, applied where tile-renderer.hpp:234-239 applies it.
+//
+// Two things the reference keeps private decide the adapter's shape:
+//  * yart::Camera has no accessors (core/camera.hpp: only getRay is public), so the adapter is given the camera
+//    parameters as a YartCameraDesc — the values main.cpp:32-76 passes to the Camera constructor / moveAndLookAt;
+//  * ParametricBSDF has no accessors either (bsdf/parametric.hpp:51-73), so a loaded yart::Scene cannot be
+//    flattened from outside: the device scene is imported from the asset by the library itself
+//    (yart::hip::DeviceScene::fromGltf — the same mapping as src/gltf/gltf.cpp), or described by the loader.
+// `Renderer::scene` is therefore not read; `deviceScene` is. A null deviceScene renders nothing, as a null scene
+// does in the reference (cpu/integrator.cpp:6).
+//
+// Compiled against the reference's headers by `make -C oracle ref_hip` (oracle/adapter_main.cpp) and run on the GPU
+// by tests/test_adapter.py. Needs: -I<reference>/src -I<this repo>/include -L<this repo>/yart_amd -lyart_hip.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <thread>
+#include <vector>
+
+#include <core/core.hpp>
+#include <core/renderer.hpp>
+#include <core/tonemapping.hpp>
+
+#include <yart_hip.hpp>
+
+namespace yart::hip_backend {
+
+class HipRenderer final : public yart::Renderer {
+public:
+  // TileRenderer's knobs (tile-renderer.hpp:27-32); threadCount has no meaning here
+  uint32_t samples = 64, firstWaveSamples = 64, maxWaveSamples = 128, tileSize = 64;
+  uint32_t maxDepth = 30;                              // RayIntegrator::m_maxDepth (cpu/ray-integrator.hpp:14)
+  const tonemap::Tonemap* tonemapper = nullptr;
+  const yart::hip::DeviceScene* deviceScene = nullptr;
+  YartCameraDesc cameraDesc{};                         // width / height are taken from the buffer
+
+  HipRenderer(Buffer&& buffer, const Camera& camera) noexcept
+    : Renderer(std::move(buffer), camera), m_hdr(size_t(m_buffer.width()) * m_buffer.height() * 4, 0.0f) {}
+  ~HipRenderer() { wait(); }
+
+  void render() override {
+    wait();
+    m_aborted = false;
+    m_worker = std::thread([this] {
+      const RenderData d = renderSync();
+      const auto& cb = m_aborted ? onRenderAborted : onRenderComplete;
+      if (cb) (*cb)(d);
+    });
+  }
+  void abort() override { m_aborted = true; }          // takes effect between waves (a wave is a few launches)
+  void wait() override { if (m_worker.joinable()) m_worker.join(); }
+
+  RenderData renderSync() override {
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    const uint32_t w = m_buffer.width(), h = m_buffer.height();
+    uint64_t rays = 0;
+    size_t taken = 0;
+    if (deviceScene) {
+      YartCameraDesc cam = cameraDesc;
+      cam.width = w; cam.height = h;
+      // one library call per wave of the schedule tile-renderer.hpp:264-308 defines, so that the wave callback and
+      // abort() behave as they do there; the accumulated linear frame lives in m_hdr (the reference's m_hdrBuffer)
+      size_t wave = 0;
+      uint32_t waveSamples = std::min(firstWaveSamples, samples);
+      while (taken < samples && !m_aborted) {
+        YartRenderParams p{};
+        p.samples = samples; p.first_wave_samples = std::min(firstWaveSamples, samples); p.max_wave_samples = maxWaveSamples;
+        p.tile_size = tileSize; p.max_depth = maxDepth;
+        p.background[0] = backgroundColor[0]; p.background[1] = backgroundColor[1]; p.background[2] = backgroundColor[2];
+        p.rank = 0; p.world_size = 1;
+        p.start_sample = uint32_t(taken); p.stop_sample = uint32_t(taken + waveSamples);
+        YartStats st{};
+        yart::hip::check(yart_hip_render(deviceScene->handle(), &cam, &p, m_hdr.data(), &st));
+        taken += waveSamples;
+        rays += st.rays;
+        {
+          std::unique_lock lock(m_bufferMutex);
+          for (uint32_t y = 0; y < h; y++)
+            for (uint32_t x = 0; x < w; x++) {
+              const float* px = &m_hdr[(size_t(y) * w + x) * 4];
+              const float4 hdr(px[0], px[1], px[2], px[3]);
+              m_buffer(x, y) = tonemapper ? float4((*tonemapper)(float3(hdr)), 1.0f) : hdr;   // tile-renderer.hpp:234-239
+            }
+        }
+        const auto now = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0);
+        if (onRenderWaveComplete)
+          (*onRenderWaveComplete)(RenderData{m_buffer, taken, samples, rays, now},
+                                  WaveData{wave, waveSamples, st.rays, std::chrono::milliseconds(int64_t(st.ms_total))});
+        // tile-renderer.hpp:284-289: double the wave, capped; a first wave of one sample is followed by another one
+        const size_t next = (wave > 0 || waveSamples > 1) ? std::min<size_t>(size_t(waveSamples) * 2, maxWaveSamples) : 1;
+        waveSamples = uint32_t(std::min<size_t>(next, samples - taken));
+        wave++;
+      }
+    }
+    const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0);
+    return {m_buffer, taken, samples, rays, ms};
+  }
+
+private:
+  std::vector<float> m_hdr;
+  std::thread m_worker;
+  volatile bool m_aborted = false;
+};
+
+}  // namespace yart::hip_backend

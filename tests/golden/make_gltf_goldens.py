@@ -20,6 +20,7 @@ Expected outputs (the reference's own code, through oracle/_ref/yart_ref):
     png_<case>.<C><type>.tex, jpg_<case>.<C><type>.tex    loadTexture<C>(file, type, channels) (core/texture.hpp:62-92): u32 w, h, C + bytes
     env_*.hdrtex                loadTextureHDR (core/texture.cpp:5-20): u32 w, h + float RGB
     xform.bin                   Transform(T*R*S) and node.transform * globalTransform per row (gltf.cpp:284-293)
+    gallery.agx_golden.f32      gallery.f32 through the reference's AgX tonemapper, look golden (`yart_ref tonemap`)
     gallery.f32                 the reference's render of the scene the importer made of gallery.glb + env_rle.hdr
                                 (the importer's .yscn is the input the reference gets: its loader cannot be built here)
 """
@@ -292,6 +293,9 @@ def main():
     subprocess.run([REF, "render", tmp, os.path.join(OUT, "gallery.txt"), os.path.join(OUT, "gallery.f32")], check=True,
                    stdout=subprocess.DEVNULL)
     os.remove(tmp)
+    # the reference's own AgX (host) on that frame: what a renderer with `tonemapper = &agx` leaves in its buffer
+    subprocess.run([REF, "tonemap", os.path.join(OUT, "gallery.f32"), str(p["size"][0]), str(p["size"][1]), "golden",
+                    os.path.join(OUT, "gallery.agx_golden.f32"), os.devnull], check=True)
     print({f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})
 
 

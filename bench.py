@@ -63,12 +63,14 @@ def cpu_baseline(scene, p, args):
     with tempfile.TemporaryDirectory() as td:
         sp, pp, out = os.path.join(td, "s.yscn"), os.path.join(td, "p.txt"), os.path.join(td, "o.f32")
         scene.save(sp)
-        scenes.write_params(pp, dict(p, spp=args.cpu_spp), threads=cores)
+        # the reference's own knobs only (the library's sharding / estimator keys mean nothing to it)
+        q = {k: v for k, v in p.items() if k not in ("shard_tile", "estimator", "start_sample", "stop_sample")}
+        scenes.write_params(pp, dict(q, spp=args.cpu_spp), threads=cores)
         t0 = time.perf_counter()
         r = subprocess.run([exe, "render", sp, pp, out], capture_output=True, text=True)
         wall = time.perf_counter() - t0
         if r.returncode != 0:
-            return None
+            raise SystemExit(f"bench.py: the CPU baseline ({exe}) failed: {r.stderr.strip()[-400:]}")
         info = json.loads(r.stdout.strip().splitlines()[-1])
     return {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
             "sample": f"same scene/camera, {p['size'][0]}x{p['size'][1]}, {args.cpu_spp} spp of {p['spp']}, "

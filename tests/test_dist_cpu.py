@@ -50,3 +50,17 @@ def test_two_rank_merge_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] and res[1]
+
+
+def test_bench_cpu_baseline_leg_runs_on_a_small_case():
+    """bench.py's cpu_baseline leg (the compiled reference, or the oracle, timed on the host cores) on a 32x32 case,
+    with the library-only keys the bench carries in its parameter dict."""
+    import argparse
+    import bench
+    from yart_amd import scenes
+    scene, p = scenes.cornell(32, 32, 2, 3)
+    cb = bench.cpu_baseline(scene, dict(p, shard_tile=16, estimator=0), argparse.Namespace(cpu_spp=1))
+    if cb is None:
+        import pytest
+        pytest.skip("neither oracle/_ref/yart_ref nor oracle/_build/yart_oracle is built")
+    assert cb["unit"] == "Msamples/s" and cb["value"] > 0 and cb["kind"] in ("reference", "port") and cb["cores"] >= 1

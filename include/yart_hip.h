@@ -27,7 +27,8 @@ enum {
   YART_E_INVALID = -1,    /* bad descriptor (null pointer, index out of range, ...) */
   YART_E_NO_DEVICE = -2,  /* no usable HIP device */
   YART_E_HIP = -3,        /* a HIP runtime call failed */
-  YART_E_IO = -4          /* scene file could not be read */
+  YART_E_IO = -4,         /* scene file could not be read */
+  YART_ABORTED = 1        /* yart_hip_render_waves: the wave callback asked to stop (the frame holds the waves done) */
 };
 
 /* Texture as the reference holds it after load (src/core/texture.hpp:21-49):
@@ -197,7 +198,15 @@ int yart_hip_gltf_to_yscn(const char* gltf_path, const YartImportOptions* opts, 
  * reference's m_hdrBuffer (tile-renderer.hpp:93, tonemapper == nullptr). */
 int yart_hip_render(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
                     float* out_rgba, YartStats* stats);
-/* Same, writing a DEVICE buffer (e.g. a torch tensor's data_ptr) on `stream`
+/* Same, one wave of the schedule at a time (tile-renderer.hpp:264-289): after every wave out_rgba holds the frame
+ * blended so far and on_wave is called — what Renderer::onRenderWaveComplete reports (renderer.hpp:33-38, 56) —
+ * with that wave's statistics; a non-zero return stops the render after this wave, as Renderer::abort() does
+ * between tiles, and the call returns YART_ABORTED. on_wave may be NULL. */
+typedef int (*YartWaveCallback)(void* user, const YartStats* wave_stats, uint32_t wave, uint32_t wave_samples,
+                                uint32_t samples_taken, uint32_t total_samples);
+int yart_hip_render_waves(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                          float* out_rgba, YartStats* stats, YartWaveCallback on_wave, void* user);
+/* Same as yart_hip_render, writing a DEVICE buffer (e.g. a torch tensor's data_ptr) on `stream`
  * (hipStream_t, may be NULL); returns after the work has been enqueued and
  * completed on that stream. */
 int yart_hip_render_device(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,

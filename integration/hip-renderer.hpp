@@ -54,52 +54,50 @@ public:
   void wait() override { if (m_worker.joinable()) m_worker.join(); }
 
   RenderData renderSync() override {
-    const auto t0 = std::chrono::high_resolution_clock::now();
-    const uint32_t w = m_buffer.width(), h = m_buffer.height();
-    uint64_t rays = 0;
-    size_t taken = 0;
+    m_t0 = std::chrono::high_resolution_clock::now();
+    m_taken = 0; m_rays = 0;
     if (deviceScene) {
       YartCameraDesc cam = cameraDesc;
-      cam.width = w; cam.height = h;
-      // one library call per wave of the schedule tile-renderer.hpp:264-308 defines, so that the wave callback and
-      // abort() behave as they do there; the accumulated linear frame lives in m_hdr (the reference's m_hdrBuffer)
-      size_t wave = 0;
-      uint32_t waveSamples = std::min(firstWaveSamples, samples);
-      while (taken < samples && !m_aborted) {
-        YartRenderParams p{};
-        p.samples = samples; p.first_wave_samples = std::min(firstWaveSamples, samples); p.max_wave_samples = maxWaveSamples;
-        p.tile_size = tileSize; p.max_depth = maxDepth;
-        p.background[0] = backgroundColor[0]; p.background[1] = backgroundColor[1]; p.background[2] = backgroundColor[2];
-        p.rank = 0; p.world_size = 1;
-        p.start_sample = uint32_t(taken); p.stop_sample = uint32_t(taken + waveSamples);
-        YartStats st{};
-        yart::hip::check(yart_hip_render(deviceScene->handle(), &cam, &p, m_hdr.data(), &st));
-        taken += waveSamples;
-        rays += st.rays;
-        {
-          std::unique_lock lock(m_bufferMutex);
-          for (uint32_t y = 0; y < h; y++)
-            for (uint32_t x = 0; x < w; x++) {
-              const float* px = &m_hdr[(size_t(y) * w + x) * 4];
-              const float4 hdr(px[0], px[1], px[2], px[3]);
-              m_buffer(x, y) = tonemapper ? float4((*tonemapper)(float3(hdr)), 1.0f) : hdr;   // tile-renderer.hpp:234-239
-            }
-        }
-        const auto now = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0);
-        if (onRenderWaveComplete)
-          (*onRenderWaveComplete)(RenderData{m_buffer, taken, samples, rays, now},
-                                  WaveData{wave, waveSamples, st.rays, std::chrono::milliseconds(int64_t(st.ms_total))});
-        // tile-renderer.hpp:284-289: double the wave, capped; a first wave of one sample is followed by another one
-        const size_t next = (wave > 0 || waveSamples > 1) ? std::min<size_t>(size_t(waveSamples) * 2, maxWaveSamples) : 1;
-        waveSamples = uint32_t(std::min<size_t>(next, samples - taken));
-        wave++;
-      }
+      cam.width = m_buffer.width(); cam.height = m_buffer.height();
+      YartRenderParams p{};
+      p.samples = samples; p.first_wave_samples = std::min(firstWaveSamples, samples); p.max_wave_samples = maxWaveSamples;
+      p.tile_size = tileSize; p.max_depth = maxDepth;
+      p.background[0] = backgroundColor[0]; p.background[1] = backgroundColor[1]; p.background[2] = backgroundColor[2];
+      p.rank = 0; p.world_size = 1;
+      YartStats st{};
+      // one library call; it walks the wave schedule of tile-renderer.hpp:264-289 and reports every wave with the
+      // frame blended so far in m_hdr (the reference's m_hdrBuffer); a non-zero return from the callback is abort()
+      const int rc = yart_hip_render_waves(deviceScene->handle(), &cam, &p, m_hdr.data(), &st, &HipRenderer::onWave, this);
+      if (rc != YART_ABORTED) yart::hip::check(rc);
     }
-    const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0);
-    return {m_buffer, taken, samples, rays, ms};
+    return {m_buffer, m_taken, samples, m_rays, elapsed()};
   }
 
 private:
+  static int onWave(void* user, const YartStats* st, uint32_t wave, uint32_t waveSamples, uint32_t taken, uint32_t total) {
+    HipRenderer& r = *static_cast<HipRenderer*>(user);
+    const uint32_t w = r.m_buffer.width(), h = r.m_buffer.height();
+    {
+      std::unique_lock lock(r.m_bufferMutex);
+      for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+          const float* px = &r.m_hdr[(size_t(y) * w + x) * 4];
+          const float4 hdr(px[0], px[1], px[2], px[3]);
+          r.m_buffer(x, y) = r.tonemapper ? float4((*r.tonemapper)(float3(hdr)), 1.0f) : hdr;   // tile-renderer.hpp:234-239
+        }
+    }
+    r.m_taken = taken; r.m_rays += st->rays;
+    if (r.onRenderWaveComplete)
+      (*r.onRenderWaveComplete)(RenderData{r.m_buffer, taken, total, r.m_rays, r.elapsed()},
+                                WaveData{wave, waveSamples, st->rays, std::chrono::milliseconds(int64_t(st->ms_device))});
+    return r.m_aborted ? 1 : 0;
+  }
+  std::chrono::milliseconds elapsed() const {
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - m_t0);
+  }
+  std::chrono::high_resolution_clock::time_point m_t0;
+  size_t m_taken = 0;
+  uint64_t m_rays = 0;
   std::vector<float> m_hdr;
   std::thread m_worker;
   volatile bool m_aborted = false;

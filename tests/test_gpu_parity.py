@@ -350,3 +350,38 @@ def test_resumed_accumulation_equals_uninterrupted_render(api):
     with pytest.raises(api.YartError):
         scene.render(dict(p, start_sample=5), accumulated=first)
     scene.close()
+
+
+def test_wave_callback_and_abort(api):
+    """yart_hip_render_waves: the per-wave callback of Renderer::onRenderWaveComplete and abort between waves.
+    cornell_waves = 16 spp as waves of 8 + 8 (the reference rendered its golden that way)."""
+    base = os.path.join(GOLDEN, "cornell_waves")
+    p = load_params(base + ".txt")
+    ref = np.fromfile(base + ".f32", np.float32).reshape(p["size"][1], p["size"][0], 4)
+    scene = api.DeviceScene(base + ".yscn", device=0)
+    seen = []
+    img, st, aborted = scene.render_waves(p, lambda frame, info: seen.append((dict(info), frame.copy())) and None)
+    assert not aborted and st["waves"] == 2
+    assert [s[0] for s in seen] == [dict(wave=0, wave_samples=8, samples_taken=8, total_samples=16),
+                                    dict(wave=1, wave_samples=8, samples_taken=16, total_samples=16)]
+    plain, _ = scene.render(p)
+    assert np.array_equal(img.view(np.uint32), plain.view(np.uint32))
+    assert rmse(img, ref) < RMSE_TOL and np.mean(np.all(img.view(np.uint32) == ref.view(np.uint32), axis=-1)) > 0.5
+    # the frame handed to the first callback is the render of the first wave alone
+    first, _ = scene.render(dict(p, stop_sample=8))
+    assert np.array_equal(seen[0][1].view(np.uint32), first.view(np.uint32))
+    # abort after the first wave: that frame is returned
+    img2, st2, aborted2 = scene.render_waves(p, lambda frame, info: True)
+    assert aborted2 and st2["waves"] == 1 and np.array_equal(img2.view(np.uint32), first.view(np.uint32))
+    # an exception in the callback stops the render and is re-raised
+    class Boom(Exception):
+        pass
+
+    def bad(frame, info):
+        raise Boom()
+    with pytest.raises(Boom):
+        scene.render_waves(p, bad)
+    # no callback: same as render()
+    img3, _, _ = scene.render_waves(p)
+    assert np.array_equal(img3.view(np.uint32), plain.view(np.uint32))
+    scene.close()

@@ -118,6 +118,11 @@ class Stats(C.Structure):
 ESTIMATOR_GMON, ESTIMATOR_MEAN, ESTIMATOR_MON, ESTIMATOR_GMONB = 0, 1, 2, 3
 
 
+YART_ABORTED = 1
+# int on_wave(void* user, const YartStats* wave_stats, wave, wave_samples, samples_taken, total_samples)
+WAVE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+
+
 class ImportOptions(C.Structure):
     """YartImportOptions (include/yart_hip.h): the environment the frontend adds after gltf::load."""
     _fields_ = [("env_hdr_path", C.c_char_p), ("env_radius", C.c_float), ("uniform_env", C.c_uint32),
@@ -149,7 +154,7 @@ def gltf_to_yscn(gltf_path, yscn_path, env_hdr=None, env_radius=100.0, uniform_e
 EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error",
            "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
            "yart_hip_scene_load_gltf", "yart_hip_gltf_to_yscn",
-           "yart_hip_render", "yart_hip_render_device", "yart_hip_probe_samples",
+           "yart_hip_render", "yart_hip_render_waves", "yart_hip_render_device", "yart_hip_probe_samples",
            "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_debug_counters",
            "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host"]
 
@@ -176,6 +181,8 @@ def lib(instrumented: bool = False):
         L.yart_hip_scene_destroy.restype = None
         L.yart_hip_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
                                       C.c_void_p, C.POINTER(Stats)]
+        L.yart_hip_render_waves.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p,
+                                            C.POINTER(Stats), WAVE_CALLBACK, C.c_void_p]
         L.yart_hip_render_device.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
                                              C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.yart_hip_probe_samples.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
@@ -300,6 +307,33 @@ class DeviceScene:
         _check(self._L.yart_hip_render(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p),
                                      C.byref(st)))
         return out, st.asdict()
+
+    def render_waves(self, p: dict, on_wave=None, rank=0, world_size=1, flags=0, accumulated=None):
+        """Like :meth:`render`, one wave of the schedule at a time (tile-renderer.hpp:264-289).
+        ``on_wave(frame, info)`` is called after every wave with the frame blended so far (a view of the output
+        array) and ``info = dict(wave, wave_samples, samples_taken, total_samples)``; returning a true value stops
+        the render after that wave (Renderer::abort). Returns (frame, stats, aborted)."""
+        cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
+        out = np.empty((cam.height, cam.width, 4), np.float32)
+        if accumulated is not None:
+            out[...] = accumulated
+        errors = []
+
+        def trampoline(_user, _stats, wave, wave_samples, taken, total):
+            try:
+                stop = on_wave(out, dict(wave=wave, wave_samples=wave_samples, samples_taken=taken, total_samples=total))
+                return 1 if stop else 0
+            except BaseException as e:          # an exception must not unwind through the C frames
+                errors.append(e)
+                return 1
+        cb = WAVE_CALLBACK(trampoline) if on_wave else WAVE_CALLBACK()
+        rc = self._L.yart_hip_render_waves(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p),
+                                           C.byref(st), cb, None)
+        if errors:
+            raise errors[0]
+        if rc != YART_ABORTED:
+            _check(rc, self._L)
+        return out, st.asdict(), rc == YART_ABORTED
 
     def render_into(self, tensor, p: dict, rank=0, world_size=1, flags=0, stream=None):
         """Render into a CUDA/HIP torch tensor of shape (H, W, 4) float32 (device memory)."""

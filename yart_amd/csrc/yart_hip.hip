@@ -722,6 +722,50 @@ int yart_hip_render(YartScene* scene, const YartCameraDesc* cam, const YartRende
   });
 }
 
+int yart_hip_render_waves(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                          float* out_rgba, YartStats* stats, YartWaveCallback on_wave, void* user) {
+  bool aborted = false;
+  const int rc = guarded([&] {
+    require(scene && out_rgba, "scene / output pointer is null");
+    validate(cam, params);
+    std::lock_guard<std::mutex> lock(scene->mu);
+    auto t0 = std::chrono::high_resolution_clock::now();
+    HIP_CHECK(hipSetDevice(scene->device));
+    const size_t n = size_t(cam->width) * cam->height * 4;
+    scene->hdr.ensure(n);
+    const uint32_t stop = params->stop_sample ? params->stop_sample : params->samples;
+    if (params->start_sample > 0) HIP_CHECK(hipMemcpy(scene->hdr.p, out_rgba, n * sizeof(float), hipMemcpyHostToDevice));
+    YartStats total{};
+    // the wave schedule of tile-renderer.hpp:264-289 (renderToDevice walks the same one): w0 = min(first, samples),
+    // then min(2 w, max) — a first wave of one sample is followed by another single one
+    uint64_t remaining = params->samples, wave = 0;
+    uint64_t waveSamples = std::min<uint64_t>(params->first_wave_samples, params->samples);
+    while (waveSamples > 0 && !aborted) {
+      const uint32_t taken = uint32_t(params->samples - remaining);
+      if (taken >= params->start_sample && taken < stop) {
+        YartRenderParams q = *params;
+        q.start_sample = taken; q.stop_sample = uint32_t(taken + waveSamples);
+        YartStats st{};
+        renderToDevice(*scene, *cam, q, scene->hdr.p, nullptr, &st);
+        HIP_CHECK(hipMemcpy(out_rgba, scene->hdr.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        total.rays += st.rays; total.waves += st.waves; total.ms_device += st.ms_device;
+        total.ms_extend += st.ms_extend; total.ms_shade += st.ms_shade; total.ms_connect += st.ms_connect; total.ms_gmon += st.ms_gmon;
+        total.ms_traverse += st.ms_traverse; total.launches_traverse += st.launches_traverse;
+        st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+        if (on_wave && on_wave(user, &st, uint32_t(wave), uint32_t(waveSamples), uint32_t(taken + waveSamples), params->samples) != 0)
+          aborted = true;
+      }
+      remaining -= waveSamples;
+      const uint64_t next = (wave > 0 || waveSamples > 1) ? std::min<uint64_t>(waveSamples * 2, params->max_wave_samples) : 1;
+      waveSamples = std::min(next, remaining);
+      wave++;
+    }
+    total.ms_total = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    if (stats) *stats = total;
+  });
+  return rc == YART_OK && aborted ? YART_ABORTED : rc;
+}
+
 int yart_hip_probe_samples(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
                            uint32_t n, const uint32_t* xys, float* out_rgb, uint64_t* out_rays) {
   return guarded([&] {

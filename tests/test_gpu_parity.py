@@ -385,3 +385,38 @@ def test_wave_callback_and_abort(api):
     img3, _, _ = scene.render_waves(p)
     assert np.array_equal(img3.view(np.uint32), plain.view(np.uint32))
     scene.close()
+
+
+def test_python_tile_renderer_mirror(api):
+    """api.HipTileRenderer: TileRenderer's knobs and calls (tile-renderer.hpp:25-115) on the Python side."""
+    base = os.path.join(GOLDEN, "cornell_waves")
+    p = load_params(base + ".txt")
+    w, h = p["size"]
+    ref = np.fromfile(base + ".f32", np.float32).reshape(h, w, 4)
+    r = api.HipTileRenderer(w, h, {k: p[k] for k in ("focal", "fnumber", "eye", "target", "up", "exposure")})
+    empty = r.render_sync()                                     # null scene: nothing happens (integrator.cpp:6)
+    assert empty.samples_taken == 0 and not empty.buffer.any()
+    r.scene = api.DeviceScene(base + ".yscn", device=0)
+    r.samples, r.first_wave_samples, r.max_wave_samples, r.max_depth = p["spp"], p["first_wave"], p["max_wave"], p["depth"]
+    waves = []
+    r.on_render_wave_complete = lambda d, info: waves.append((d.samples_taken, info["wave_samples"]))
+    done = []
+    r.on_render_complete = done.append
+    r.render(); r.wait()
+    assert waves == [(8, 8), (16, 8)] and len(done) == 1 and done[0].samples_taken == 16
+    assert rmse(done[0].buffer, ref) < RMSE_TOL
+    assert np.mean(np.all(done[0].buffer.view(np.uint32) == ref.view(np.uint32), axis=-1)) > 0.5
+    # abort from the wave callback's thread: the aborted callback fires with the first wave's frame
+    aborted = []
+    r.on_render_complete, r.on_render_aborted = None, aborted.append
+    r.on_render_wave_complete = lambda d, info: r.abort()
+    r.render(); r.wait()
+    assert len(aborted) == 1 and aborted[0].samples_taken == 8
+    # tonemapper: the exposed buffer is the AgX-mapped frame
+    r.on_render_aborted = r.on_render_wave_complete = None
+    r.tonemapper = "golden"
+    mapped = r.render_sync()
+    want, _ = api.tonemap(done[0].buffer, "golden")
+    same = (mapped.buffer.view(np.uint32) == want.view(np.uint32)) | (np.isnan(mapped.buffer) & np.isnan(want))
+    assert same.all()
+    r.scene.close()

@@ -403,9 +403,11 @@ class HipTileRenderer:
         self.max_depth = 30               # RayIntegrator::m_maxDepth, ray-integrator.hpp:14
         self.background_color = (0.0, 0.0, 0.0)
         self.scene: Optional[DeviceScene] = None
-        self.tonemapper = None            # stays on the host (reference core/tonemapping.hpp); unused here
-        self.on_render_complete = None    # callbacks of renderer.hpp:55-58 (wave/tile granularity
-        self.on_render_aborted = None     # collapses to one call: the GPU renders a wave per launch)
+        self.tonemapper = None            # AgX look name ("none" / "golden" / "punchy") or None: linear HDR buffer
+        self.estimator = ESTIMATOR_GMON   # integrator.cpp:17-18 fixes it at compile time
+        self.on_render_complete = None    # callbacks of renderer.hpp:55-58; the tile callback has no counterpart
+        self.on_render_aborted = None     # (a wave is a handful of launches over all tiles)
+        self.on_render_wave_complete = None   # f(RenderData, dict(wave, wave_samples, samples_taken, total_samples))
         self._camera = dict(camera, size=(width, height))
         self._device = device
         self._thread: Optional[threading.Thread] = None
@@ -415,21 +417,31 @@ class HipTileRenderer:
     def _params(self):
         return dict(self._camera, spp=self.samples, first_wave=min(self.first_wave_samples, self.samples),
                     max_wave=self.max_wave_samples, tile=self.tile_size, depth=self.max_depth,
-                    background=self.background_color)
+                    background=self.background_color, estimator=self.estimator)
 
     def render_sync(self) -> RenderData:
         if self.scene is None:           # Integrator::render: "if (!scene) return" (integrator.cpp:6)
             w, h = self._camera["size"]
             return RenderData(np.zeros((h, w, 4), np.float32), 0, self.samples, 0, 0.0, {})
         t0 = time.perf_counter()
-        buf, st = self.scene.render(self._params())
+        taken = [0]
+        self._abort = False
+
+        def shown(frame):                 # tile-renderer.hpp:234-239: the exposed buffer is the tonemapped one
+            return tonemap(frame, self.tonemapper)[0] if self.tonemapper else frame
+
+        def on_wave(frame, info):
+            taken[0] = info["samples_taken"]
+            if self.on_render_wave_complete:
+                self.on_render_wave_complete(RenderData(shown(frame), info["samples_taken"], self.samples, 0,
+                                                        (time.perf_counter() - t0) * 1e3, {}), info)
+            return self._abort
+        buf, st, _ = self.scene.render_waves(self._params(), on_wave)
         ms = (time.perf_counter() - t0) * 1e3
-        self._result = RenderData(buf, self.samples, self.samples, st["rays"], ms, st)
+        self._result = RenderData(shown(buf), taken[0], self.samples, st["rays"], ms, st)
         return self._result
 
     def render(self):
-        self._abort = False
-
         def run():
             r = self.render_sync()
             cb = self.on_render_aborted if self._abort else self.on_render_complete
@@ -439,7 +451,7 @@ class HipTileRenderer:
         self._thread.start()
 
     def abort(self):
-        self._abort = True               # checked between waves in the reference; a GPU wave is one launch
+        self._abort = True               # takes effect after the wave in flight (the reference: after the tiles in flight)
 
     def wait(self):
         if self._thread:

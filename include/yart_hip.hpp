@@ -78,6 +78,11 @@ class HipTileRenderer {
     uint64_t totalRays;
     std::chrono::milliseconds totalTime;
   };
+  struct WaveData {                         // renderer.hpp:33-38
+    size_t wave, waveSamples;
+    uint64_t rays;
+    std::chrono::milliseconds time;
+  };
   template <class... Ts> using RenderCallback = std::optional<std::function<void(Ts...)>>;
 
   // knobs of TileRenderer (tile-renderer.hpp:27-32) and Renderer (renderer.hpp:52-58)
@@ -88,6 +93,7 @@ class HipTileRenderer {
   int tonemapLook = -1;                     // TileRenderer::tonemapper: -1 none (linear HDR), 0 AgX none, 1 golden, 2 punchy
   const DeviceScene* scene = nullptr;
   RenderCallback<RenderData> onRenderComplete, onRenderAborted;
+  RenderCallback<RenderData, WaveData> onRenderWaveComplete;
 
   HipTileRenderer(Buffer&& buffer, const YartCameraDesc& camera) : camera_(camera), buffer_(std::move(buffer)) {
     camera_.width = buffer_.width(); camera_.height = buffer_.height();
@@ -103,7 +109,7 @@ class HipTileRenderer {
       if (cb) (*cb)(d);
     });
   }
-  void abort() { aborted_ = true; }         // a GPU wave is a single launch; takes effect between waves
+  void abort() { aborted_ = true; }         // takes effect after the wave in flight
   void wait() { if (worker_.joinable()) worker_.join(); }
 
   RenderData renderSync() {
@@ -116,21 +122,36 @@ class HipTileRenderer {
       for (int i = 0; i < 3; i++) p.background[i] = backgroundColor[i];
       p.rank = 0; p.world_size = 1;
       p.estimator = estimator;
-      check(yart_hip_render(scene->handle(), &camera_, &p, buffer_.data(), &st));
+      taken_ = 0; t0_ = t0;
+      const int rc = yart_hip_render_waves(scene->handle(), &camera_, &p, buffer_.data(), &st, &HipTileRenderer::onWave, this);
+      if (rc != YART_ABORTED) check(rc);
       if (tonemapLook >= 0)                   // tile-renderer.hpp:234-239, on the whole frame
         check(yart_hip_tonemap_host(buffer_.data(), buffer_.width(), buffer_.height(), tonemapLook, buffer_.data(), nullptr));
     }
     auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0);
     stats_ = st;
-    return {buffer_, samples, samples, st.rays, ms};
+    return {buffer_, scene ? taken_ : 0, samples, st.rays, ms};
   }
   const YartStats& stats() const { return stats_; }
 
  private:
+  // per wave: the linear frame blended so far is in buffer_ (renderer.hpp:33-38); abort() stops after this wave
+  static int onWave(void* user, const YartStats* st, uint32_t wave, uint32_t waveSamples, uint32_t taken, uint32_t total) {
+    HipTileRenderer& r = *static_cast<HipTileRenderer*>(user);
+    r.taken_ = taken;
+    if (r.onRenderWaveComplete) {
+      auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - r.t0_);
+      (*r.onRenderWaveComplete)(RenderData{r.buffer_, taken, total, st->rays, ms},
+                                WaveData{wave, waveSamples, st->rays, std::chrono::milliseconds(int64_t(st->ms_device))});
+    }
+    return r.aborted_ ? 1 : 0;
+  }
+  size_t taken_ = 0;
+  std::chrono::high_resolution_clock::time_point t0_;
   YartCameraDesc camera_;
   Buffer buffer_;
   std::thread worker_;
-  bool aborted_ = false;
+  volatile bool aborted_ = false;
   YartStats stats_{};
 };
 

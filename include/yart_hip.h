@@ -140,6 +140,7 @@ typedef struct YartRenderParams {
 #define YART_FLAG_SHADE_SORT 2u     /* bucket each wave's 256 shade-queue entries by material before shading them
                                        (measured: +5 % shade time on the C3 scene, hence opt-in) */
 #define YART_FLAG_DIRECT_SAMPLER 8u /* evaluate every ZSobol index digit per draw (no per-render sampler tables) */
+#define YART_FLAG_NO_COMPACTION 32u  /* keep every bounce on the batch-sized path state (no copy of the survivors into a dense one) */
 #define YART_FLAG_GENERAL_TRACE 4u  /* general traversal kernels for every ray instead of lean kernels + retry */
 
 /* Renderer::RenderData counters (src/core/renderer.hpp:22-28) + per-stage device time. */

@@ -33,7 +33,7 @@ def api(built):
 
 
 PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+shade_sort": 2, "wavefront+general_trace": 4,
-                  "wavefront+direct_sampler": 8, "wavefront+no_refill": 16}
+                  "wavefront+direct_sampler": 8, "wavefront+no_refill": 16, "wavefront+no_compaction": 32}
 
 
 @pytest.mark.parametrize("pipeline", list(PIPELINE_FLAGS))

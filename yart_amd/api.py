@@ -34,6 +34,7 @@ FLAG_SHADE_SORT = 2
 FLAG_GENERAL_TRACE = 4
 FLAG_DIRECT_SAMPLER = 8
 FLAG_NO_REFILL = 16
+FLAG_NO_COMPACTION = 32
 
 
 class YartError(RuntimeError):

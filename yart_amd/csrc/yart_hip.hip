@@ -272,6 +272,9 @@ struct YartScene {
   DevBuf<uint32_t> pixels; DevBuf<float> L; DevBuf<uint32_t> cursor; DevBuf<unsigned long long> counters;
   DevBuf<uint64_t> spill; DevBuf<float> hdr; DevBuf<uint32_t> probeIn; DevBuf<float> probeOut;
   DevBuf<f4> wf[9];                        // wavefront path state (wavefront.hpp::WfState)
+  DevBuf<f4> wfTail[2][9];                 // compacted states of the late bounces (1/2 and 1/4 of the batch)
+  DevBuf<uint32_t> wfTailMap[2];
+  DevBuf<WfDyn> wfDyn;
   DevBuf<uint32_t> qA, qB, qS, qR, wfCounters; // wavefront queues
   DevBuf<uint64_t> smpEntries, smpHash; DevBuf<uint32_t> smpSobol1;   // SamplerTables of the current render
   std::vector<uint32_t> pixelsHost;
@@ -463,8 +466,12 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
   uint64_t held = uint64_t(s.L.n) * 4 + (uint64_t(s.qA.n) + s.qB.n + s.qS.n + s.qR.n) * 4;
   for (auto& b : s.wf) held += uint64_t(b.n) * 16;
-  const uint64_t perPath = mega ? 12 : 172;
-  uint64_t maxPaths = std::max<uint64_t>((uint64_t(freeB) + held) / 2 / perPath, 1u << 20);
+  for (auto& t : s.wfTail) for (auto& b : t) held += uint64_t(b.n) * 16;
+  held += (uint64_t(s.wfTailMap[0].n) + s.wfTailMap[1].n) * 4;
+  // with compaction: two tail states of 1/2 and 1/4 of the batch (9 x 16 B + a slot map word each) = 111 B per path
+  const bool compact = !mega && !(p.flags & YART_FLAG_NO_COMPACTION);
+  const uint64_t perPath = mega ? 12 : compact ? 283 : 172;
+  uint64_t maxPaths = std::max<uint64_t>((uint64_t(freeB) + held) * (compact ? 6 : 5) / 10 / perPath, 1u << 20);
   if (!mega) maxPaths = std::min<uint64_t>(maxPaths, kWfMaxPaths);
   maxPaths = std::min<uint64_t>(maxPaths, (1ull << 31) - 64);
   uint32_t chunk = uint32_t(std::min<uint64_t>(nPix ? nPix : 1, std::max<uint64_t>(maxPaths / waveCap, 1)));
@@ -472,6 +479,14 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   if (!mega) {
     const size_t np = size_t(chunk) * waveCap;
     for (auto& b : s.wf) b.ensure(np);
+    if (compact) {
+      for (int t = 0; t < 2; t++) {
+        const size_t cap = np / (t == 0 ? 2 : 4) + 64;
+        for (auto& b : s.wfTail[t]) b.ensure(cap);
+        s.wfTailMap[t].ensure(cap);
+      }
+      s.wfDyn.ensure(1);
+    }
     s.qA.ensure(np); s.qB.ensure(np); s.qS.ensure(np); s.qR.ensure(np); s.wfCounters.ensure(WC_COUNT);
   }
 
@@ -532,6 +547,18 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         a.qA = s.qA.p; a.qB = s.qB.p; a.qS = s.qS.p; a.qR = s.qR.p; a.counters = s.wfCounters.p;
         a.pixels = s.pixels.p + c0; a.nPaths = n * uint32_t(waveSamples); a.spp = uint32_t(waveSamples);
         a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p; a.stats = s.counters.p; a.spill = s.spill.p;
+        if (compact) {
+          for (int t = 0; t < 2; t++) {
+            f4** f = &a.tail[t].ray0;                  // the nine pointers of WfState, in declaration order
+            for (int k = 0; k < 9; k++) f[k] = s.wfTail[t][k].p;
+            a.tailMap[t] = s.wfTailMap[t].p;
+            a.tailCap[t] = a.nPaths / (t == 0 ? 2u : 4u);
+          }
+          WfDyn d0{};
+          d0.st = a.st; d0.slotMap = nullptr; d0.extent = a.nPaths; d0.inTail = 0;
+          HIP_CHECK(hipMemcpyAsync(s.wfDyn.p, &d0, sizeof(d0), hipMemcpyHostToDevice, stream));
+          a.dyn = s.wfDyn.p;
+        }
         const uint32_t init[WC_COUNT] = {a.nPaths, 0, 0, 0, 0, 0, 0, 0};
         HIP_CHECK(hipMemcpyAsync(s.wfCounters.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
         tShade.begin(stream);
@@ -573,6 +600,13 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
           HIP_CHECK(hipGetLastError());
           std::swap(a.qA, a.qB);
+          if (compact && bounce >= 1 && bounce + 1 < rc.maxDepth) {     // Russian roulette starts thinning at depth 2
+            tShade.begin(stream);
+            hipLaunchKernelGGL(k_wf_compact, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(k_wf_compact_commit, dim3(1), dim3(64), 0, stream, a);
+            HIP_CHECK(hipGetLastError());
+            tShade.end(stream);
+          }
         }
       }
       GmonArgs g{};

@@ -170,6 +170,7 @@ def main():
     if not args.no_roofline and world == 1:
         # exact test counters from the instrumented twin library (one untimed pass; the
         # workload is deterministic so the counts are those of every timed pass)
+        dscene.close()           # hand its batch buffers back: the counting pass is one batch too, launch for launch
         ds2 = api.DeviceScene(scene, device=local_rank, instrumented=True)
         _, st2 = ds2.render(p, flags=args.flags)
         ds2.close()

@@ -154,7 +154,18 @@ __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
   if (valid && int(sub) < m) {
     f3 acc = mk3(0); uint32_t cnt = 0;
     const float* p = a.L + size_t(pi) * a.spp * 3;
-    for (uint32_t s = sub; s < a.spp; s += uint32_t(m)) {       // bucket k mod m, increasing k
+    // bucket k mod m, increasing k; four samples' loads in flight, accumulated in order
+    const uint32_t um = uint32_t(m);
+    uint32_t s = sub;
+    for (; s + 3u * um < a.spp; s += 4u * um) {
+      f3 v[4];
+      for (uint32_t j = 0; j < 4u; j++) { const float* q = p + size_t(s + j * um) * 3; v[j] = mk3(q[0], q[1], q[2]); }
+      for (uint32_t j = 0; j < 4u; j++) {
+        const f3 w = v[j] * a.exposureScale;
+        if (estimatorAccepts(a.kind, w)) { acc += w; cnt++; }
+      }
+    }
+    for (; s < a.spp; s += um) {
       f3 v = mk3(p[s * 3], p[s * 3 + 1], p[s * 3 + 2]) * a.exposureScale;
       if (estimatorAccepts(a.kind, v)) { acc += v; cnt++; }
     }

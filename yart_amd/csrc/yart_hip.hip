@@ -146,7 +146,9 @@ constexpr int kGmonLanes = 16;
 static_assert(kGmonMax <= kGmonLanes, "one lane per bucket");
 constexpr int kGmonPixPerBlock = kBlock / kGmonLanes;
 __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
-  __shared__ float sAcc[kGmonPixPerBlock][kGmonMax][4];
+  // bucket sums / counts live in LDS and are sorted there: private arrays with run-time indices would be scratch
+  __shared__ f3 sAcc[kGmonPixPerBlock][kGmonMax];
+  __shared__ uint32_t sCnt[kGmonPixPerBlock][kGmonMax];
   const uint32_t sub = threadIdx.x & (kGmonLanes - 1), lp = threadIdx.x / kGmonLanes;
   const uint32_t pi = blockIdx.x * kGmonPixPerBlock + lp;
   const bool valid = pi < a.nPixels;
@@ -169,17 +171,12 @@ __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
       f3 v = mk3(p[s * 3], p[s * 3 + 1], p[s * 3 + 2]) * a.exposureScale;
       if (estimatorAccepts(a.kind, v)) { acc += v; cnt++; }
     }
-    sAcc[lp][sub][0] = acc.x; sAcc[lp][sub][1] = acc.y; sAcc[lp][sub][2] = acc.z;
-    sAcc[lp][sub][3] = __uint_as_float(cnt);
+    sAcc[lp][sub] = acc;
+    sCnt[lp][sub] = cnt;
   }
   __syncthreads();
   if (valid && sub == 0) {
-    f3 acc[kGmonMax]; uint32_t cnt[kGmonMax];
-    for (int b = 0; b < m; b++) {
-      acc[b] = mk3(sAcc[lp][b][0], sAcc[lp][b][1], sAcc[lp][b][2]);
-      cnt[b] = __float_as_uint(sAcc[lp][b][3]);
-    }
-    f3 v = estimatorFinish(a.kind, acc, cnt, m, a.spp);
+    f3 v = estimatorFinish(a.kind, sAcc[lp], sCnt[lp], m, a.spp);
     const uint32_t pk = a.pixels[pi];
     float* o = a.hdr + (size_t(pk >> 16) * a.width + (pk & 0xffffu)) * 4;
     // m_hdrBuffer = current * wCurrent + wave * wWave   (tile-renderer.hpp:230)

@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from yart_amd import api, scenes
-if os.environ.get("YART_LIB"):
+if os.environ.get("YART_LIB") and os.environ["YART_LIB"] != "main":
     api.LIB_PATH = os.path.join(ROOT, "yart_amd", "_variants", os.environ["YART_LIB"] + ".so")
 flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 w, h, spp = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (480, 270, 32)

@@ -260,8 +260,25 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
   }
   if (!(res.scatter & (SC_REFLECTED | SC_TRANSMITTED))) return WF_TERMINATED;
 
+  // Everything of the continuing path that does not depend on the light sample is computed — and the new ray
+  // stored — before the NEE block, so that the BSDF sample does not have to wait in registers (or scratch) for
+  // the end of it. The old throughput stays in p.att until then (NEE's MIS terms use it).
+  const f3 fcos = res.f * absDot(res.wi, hit.n);
+  f3 newAtt = p.att * (fcos / res.pdf);
+  if (hit.backSide) newAtt *= matAttenuation(mt, hit.t);
+  {
+    WfPath q;
+    q.o = hit.p; q.d = res.wi; q.lastPdf = res.pdf; q.accRoughness = p.accRoughness + res.roughness;
+    wfStoreRay(s, i, q);
+    uint32_t fl = (depth + 1) & WF_DEPTH_MASK;
+    if (res.scatter & SC_SPECULAR) fl |= WF_SPECULAR;
+    if (q.accRoughness > 0.5f) fl |= WF_REGULARIZED;
+    p.flags = fl;
+  }
+  const bool nee = !(res.scatter & (SC_EMITTED | SC_SPECULAR));
+
   bool shadow = false;
-  if (!(res.scatter & (SC_EMITTED | SC_SPECULAR))) {            // L += attenuation * Ld(...)   (:79-80)
+  if (nee) {                                                    // L += attenuation * Ld(...)   (:79-80)
     if (sc.nLights != 0) {                                      // Ld set-up (:111-124)
       float ucl = get1D(p.smp, rc.sampler);
       f2 ul = get2D(p.smp, rc.sampler, sobol);
@@ -287,16 +304,7 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
     // which matters only when the throughput is already inf/NaN — kept for bit parity
     if (!shadow) p.L += p.att * mk3(0.0f);
   }
-  f3 fcos = res.f * absDot(res.wi, hit.n);
-  p.att *= fcos / res.pdf;
-  if (hit.backSide) p.att *= matAttenuation(mt, hit.t);
-  p.o = hit.p; p.d = res.wi;
-  p.accRoughness += res.roughness;
-  p.lastPdf = res.pdf;
-  uint32_t fl = (depth + 1) & WF_DEPTH_MASK;
-  if (res.scatter & SC_SPECULAR) fl |= WF_SPECULAR;
-  if (p.accRoughness > 0.5f) fl |= WF_REGULARIZED;
-  p.flags = fl;
+  p.att = newAtt;
   return shadow ? WF_SHADOW : WF_CONTINUE;
 }
 

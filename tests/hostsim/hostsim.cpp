@@ -461,6 +461,7 @@ static int doBvhCheck(const char* scenePath, unsigned threads) {
   auto loaded = loadSceneFile(scenePath);
   double msSerial = 0, msParallel = 0;
   size_t nodes = 0, tris = 0;
+  uint32_t maxLeaf = 0;
   for (uint32_t m = 0; m < loaded->desc.n_meshes; m++) {
     const YartMeshDesc& md = loaded->desc.meshes[m];
     SahBvhBuilder a, b;
@@ -478,9 +479,10 @@ static int doBvhCheck(const char* scenePath, unsigned threads) {
       return 3;
     }
     nodes += a.nodes.size(); tris += md.n_faces;
+    for (const BvhNode& n : a.nodes) maxLeaf = std::max(maxLeaf, n.span);
   }
-  std::printf("{\"bvhcheck\": \"ok\", \"meshes\": %u, \"triangles\": %zu, \"nodes\": %zu, \"threads\": %u, \"ms_serial\": %.1f, \"ms_parallel\": %.1f}\n",
-              loaded->desc.n_meshes, tris, nodes, threads, msSerial, msParallel);
+  std::printf("{\"bvhcheck\": \"ok\", \"meshes\": %u, \"triangles\": %zu, \"nodes\": %zu, \"max_leaf_span\": %u, \"threads\": %u, \"ms_serial\": %.1f, \"ms_parallel\": %.1f}\n",
+              loaded->desc.n_meshes, tris, nodes, maxLeaf, threads, msSerial, msParallel);
   return 0;
 }
 

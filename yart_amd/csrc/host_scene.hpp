@@ -206,6 +206,9 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
         if (bn.span > 0) {
           for (uint32_t k = 0; k < bn.span; k++)
             if (im.leafTris[md.leafOffset + bn.leftFirst + k].matFlags & MAT_HAS_ALPHA) hasAlpha[n] = 1;
+          // the leaf's span, for stack entries whose 5-bit span field saturated (traverse.hpp::leafSpan)
+          require(bn.span < (1u << (32 - kLeafSpanShift)), "mesh: a BVH leaf of 2^24 or more triangles is not supported");
+          im.leafTris[md.leafOffset + bn.leftFirst].matFlags |= bn.span << kLeafSpanShift;
         } else {
           hasAlpha[n] = hasAlpha[bn.leftFirst] | hasAlpha[bn.leftFirst + 1];
         }

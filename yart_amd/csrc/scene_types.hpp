@@ -51,6 +51,9 @@ struct MaterialDev {       // bsdf/parametric.hpp:52-77
 // material (used by the lean shadow kernel to end occluded rays early, traverse.hpp).
 constexpr uint32_t kLinkIndexMask = (1u << 26) - 1u;
 constexpr uint32_t kLinkAlphaBit = 1u << 26;
+// traversal-stack link word: index | alpha bit | leaf span << 27 (5 bits, 31 = "31 or more": traverse.hpp::leafSpan
+// then reads the true span from bits 8..31 of the matFlags word of the leaf's first LeafTri)
+constexpr uint32_t kSpanShift = 27, kSpanBig = 31, kLeafSpanShift = 8;
 
 struct BvhNode {           // core/bvh.hpp:21-33 (32 bytes)
   float bmin[3];
@@ -61,7 +64,7 @@ struct BvhNode {           // core/bvh.hpp:21-33 (32 bytes)
 
 struct LeafTri {           // 48 bytes, leaf order
   float p0[3]; uint32_t triIdx;
-  float e1[3]; uint32_t matFlags;   // MAT_HAS_ALPHA | MAT_TRANSPARENT of the triangle's material
+  float e1[3]; uint32_t matFlags;   // MAT_HAS_ALPHA | MAT_TRANSPARENT of the triangle's material; first record of a leaf: | span << 8
   float e2[3]; uint32_t material;
 };
 

@@ -150,7 +150,16 @@ YART_HD void interpUVN(const SceneDev& sc, const MeshDev& mesh, uint32_t tri, fl
 //    interleaving it with other lanes' inner steps;
 //  * a stack entry carries the far child's link word (leftFirst | span << 27) and entry
 //    distance, so a pop needs no dependent node fetch before the children can be loaded.
-constexpr uint32_t kSpanShift = 27;            // index < 2^26 (checked at scene build), bit 26 = kLinkAlphaBit
+// The link word of a stack entry has 5 bits for the leaf span. The reference keeps a node as a leaf of ANY span
+// when its split is degenerate (bvh.hpp:159-161: coincident centroids, stacked duplicates), so 31 stands for
+// "31 or more" and the leaf loop then takes the true span from the leaf's first record (LeafTri::matFlags
+// bits 8..31, written at scene build for every leaf).
+YART_HD uint32_t packLink(uint32_t leftFirst, uint32_t span) {
+  return leftFirst | ((span < kSpanBig ? span : kSpanBig) << kSpanShift);
+}
+YART_HD uint32_t leafSpan(const LeafTri* leaves, uint32_t first, uint32_t span) {
+  return span < kSpanBig ? span : (leaves[first].matFlags >> kLeafSpanShift);
+}
 template <bool NEE, int MODE = TRAV_GENERAL>
 YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t nodeIdx, const RayO& ray,
                           float tMin, HitRec& hit, f3& attenuation, const TravStack& stk,
@@ -188,8 +197,7 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
           // child1 is the near one unless it was missed or (both hit and d1 > d2)
           const bool firstNear = hit1 && !(hit2 && d1 > d2);
           if (hit1 && hit2)
-            stackPush(stk, stackIdx++, firstNear ? (c2.leftFirst | (c2.span << kSpanShift))
-                                                 : (c1.leftFirst | (c1.span << kSpanShift)),
+            stackPush(stk, stackIdx++, firstNear ? packLink(c2.leftFirst, c2.span) : packLink(c1.leftFirst, c1.span),
                       firstNear ? d2 : d1);
           d = firstNear ? d1 : d2;
           leftFirst = firstNear ? c1.leftFirst : c2.leftFirst;
@@ -208,7 +216,8 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
     }
     if (!alive) break;
     // ---- leaf: triangles in index order
-    for (uint32_t i = 0; i < span; i++) {
+    const uint32_t nLeaf = leafSpan(leaves, leftFirst & kLinkIndexMask, span);
+    for (uint32_t i = 0; i < nLeaf; i++) {
       const LeafTri tr = leaves[(leftFirst & kLinkIndexMask) + i];
       YART_COUNT(nTri, 1);
       const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);

@@ -440,7 +440,9 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const bool general = (p.flags & YART_FLAG_GENERAL_TRACE) != 0;
   const bool ident = s.host.allIdentity;
   const bool refill = (p.flags & YART_FLAG_NO_REFILL) == 0;
-  const bool chunked = s.host.nodes.size() > 64;       // trace_lean.hpp: node candidate mask in chunks of 64
+  // trace_lean.hpp keeps one 64-bit node candidate mask per ray and uses the all-ones mask as its "new ray"
+  // marker, which a ray that can reach all of exactly 64 nodes would keep: 64 nodes and more go to the chunked form
+  const bool chunked = s.host.nodes.size() >= 64;
   auto kExtendFast = !refill ? (ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>)
                    : chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_extend_lean<TRAV_FAST, true>)
                              : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_extend_lean<TRAV_FAST, false>);

@@ -614,3 +614,23 @@ def instances(width=96, height=96, spp=4, depth=4, n_instances=70, groups=4, see
             s.add_node(cube, gi, f2, i2)
     s.create_area_lights()
     return s, p
+
+
+def stacked_leaves(width=96, height=96, spp=4, depth=4, stacks=(40, 32, 64, 31, 33)):
+    """Cornell room + cards made of `n` coincident copies of the same two triangles (n from `stacks`), the
+    copies cycling through four materials. Every copy of a triangle has the same centroid, so the reference's
+    SAH split degenerates and the node stays a leaf of arbitrary span (bvh.hpp:159-161) — beyond the 5-bit span
+    field of the device's traversal-stack link word (traverse.hpp::packLink / leafSpan); of several equal-t hits
+    the first in leaf order wins (`hit.t <= t` rejects the later ones, ray-integrator.cpp:196)."""
+    s, p = cornell(width, height, spp, depth)
+    mats = [s.add_material(Material(base=c, roughness=r, metallic=m)) for c, r, m in
+            (((0.9, 0.2, 0.2), 1.0, 0.0), ((0.2, 0.9, 0.2), 0.4, 0.0), ((0.2, 0.3, 0.9), 0.2, 1.0), ((0.9, 0.8, 0.2), 0.7, 0.0))]
+    b = MeshBuilder()
+    for k, n in enumerate(stacks):
+        x0 = -4.0 + 8.0 * k / max(1, len(stacks)); x1 = x0 + 6.0 / max(1, len(stacks))
+        y0, y1, z = 1.0 + 0.9 * (k % 3), 3.5 + 0.9 * (k % 3), 1.0 - 0.7 * k
+        for c in range(n):
+            b.quad((x0, y0, z), (x1, y0, z), (x1, y1, z), (x0, y1, z), mats[(c + k) % 4])
+    s.add_node(s.add_mesh(b.build()))
+    s.create_area_lights()
+    return s, p

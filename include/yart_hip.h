@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YART_HIP_ABI_VERSION 1
+#define YART_HIP_ABI_VERSION 2
 
 enum {
   YART_OK = 0,
@@ -128,6 +128,12 @@ typedef struct YartRenderParams {
    * reference's unit of parallel work. Which process renders a pixel does not change it (the sampler only
    * knows tile_size), so a smaller block only evens out the load between GPUs. */
   uint32_t shard_tile;
+  /* Upper bound on the (pixel, sample) paths in flight per batch; 0 = as many as the free device memory holds
+   * (the whole 1080p x 256 spp frame on a 288 GB MI355X). A wave is rendered batch by batch over this rank's
+   * pixels in tile order, every batch through all bounces and the estimator, so a smaller batch means finished
+   * tiles arrive earlier (yart_hip_render_tiles) and less memory is held, at the price of more launches. The
+   * frame does not depend on it. */
+  uint32_t max_batch_paths;
 } YartRenderParams;
 #define YART_ESTIMATOR_GMON 0u      /* core/estimator.hpp:148-198 */
 #define YART_ESTIMATOR_MEAN 1u      /* :29-46 */

@@ -110,10 +110,11 @@ static int doKat(const Scene& sc, const yscn::SceneFile& sf, const params::Param
   integ.scene = &sc; integ.cam = &cam; integ.sampler = &sampler; integ.maxDepth = p.depth;
   integ.background = V3(p.background[0], p.background[1], p.background[2]);
   {
-    std::vector<float> fo; std::vector<int64_t> io;
+    std::vector<float> fo, ro6; std::vector<int64_t> io;
     for (size_t i = 0; i + 1 < p.probePixels.size(); i += 2) {
       V3 ro, rd;
       cam.ray(p.probePixels[i], p.probePixels[i + 1], V2{0.5f, 0.5f}, V2{0.5f, 0.5f}, ro, rd);
+      push3(ro6, ro); push3(ro6, rd);
       Hit h;
       bool hit = integ.testNode(Ray(ro, rd), 0.001f, h, *sc.root);
       io.push_back(hit);
@@ -122,7 +123,7 @@ static int doKat(const Scene& sc, const yscn::SceneFile& sf, const params::Param
       fo.push_back(h.t); fo.push_back(h.uv.x); fo.push_back(h.uv.y);
       push3(fo, h.p); push3(fo, h.n); push3(fo, h.tg);
     }
-    w.i64("hits_i", io); w.f32("hits_f", fo);
+    w.i64("hits_i", io); w.f32("hits_f", fo); w.f32("hit_rays", ro6);
   }
   {
     std::vector<float> fo; std::vector<int64_t> io;
@@ -211,8 +212,22 @@ static int doRender(const Scene& sc, const params::Params& p, const std::string&
   for (uint32_t y = 0; y < (H + T - 1) / T; y++)
     for (uint32_t x = 0; x < (W + T - 1) / T; x++)
       tiles.push_back({x * T, y * T, std::min(T, W - x * T), std::min(T, H - y * T)});
+  // shard_* keys: only the pixel blocks the library deals to rank R of N (blocks of shard_tile pixels numbered in
+  // Morton order of their block coordinates, block k to rank k % N) — include/yart_hip.h YartRenderParams
+  const uint32_t ST = p.shardTile ? p.shardTile : T, bx = (W + ST - 1) / ST, by = (H + ST - 1) / ST;
+  std::vector<uint8_t> mine(size_t(bx) * by, 1);
+  if (p.shardWorld > 1) {
+    std::vector<std::pair<uint64_t, uint32_t>> order;
+    for (uint32_t y = 0; y < by; y++)
+      for (uint32_t x = 0; x < bx; x++) order.push_back({encodeMorton2(x, y), y * bx + x});
+    std::sort(order.begin(), order.end());
+    for (size_t k = 0; k < order.size(); k++) mine[order[k].second] = (k % p.shardWorld) == p.shardRank;
+  }
+  uint64_t nPixelsMine = 0;
+  for (uint32_t y = 0; y < H; y++)
+    for (uint32_t x = 0; x < W; x++) nPixelsMine += mine[size_t(y / ST) * bx + x / ST];
   unsigned nt = p.threads ? p.threads : std::thread::hardware_concurrency();
-  std::atomic<uint64_t> totalRays{0};
+  std::atomic<uint64_t> totalRays{0}, totalBox{0}, totalTri{0}, totalTrav{0}, totalShade{0};
   auto t0 = std::chrono::high_resolution_clock::now();
   // wave schedule, tile-renderer.hpp:121-124, 284-289
   uint64_t remaining = p.spp, wave = std::min(p.firstWave, p.spp), current = 0;
@@ -234,6 +249,7 @@ static int doRender(const Scene& sc, const params::Params& p, const std::string&
           const Tile& tl = tiles[ti];
           for (uint32_t j = 0; j < tl.h; j++)
             for (uint32_t i = 0; i < tl.w; i++) {
+              if (!mine[size_t((j + tl.y) / ST) * bx + (i + tl.x) / ST]) continue;
               GMoN est(int32_t(wave), 15);                                   // integrator.cpp:17
               for (uint32_t s = 0; s < wave; s++)
                 est.add(integ.samplePixel(i + tl.x, j + tl.y, s + uint32_t(before)) * ev);
@@ -243,7 +259,7 @@ static int doRender(const Scene& sc, const params::Params& p, const std::string&
               for (int c = 0; c < 4; c++) o[c] = o[c] * wCur + wv[c] * wWave;   // tile-renderer.hpp:230
             }
         }
-        totalRays += integ.rays;
+        totalRays += integ.rays; totalBox += integ.nBox; totalTri += integ.nTri; totalTrav += integ.nTrav; totalShade += integ.nShade;
       });
     for (auto& t : th) t.join();
     remaining -= wave;
@@ -256,8 +272,11 @@ static int doRender(const Scene& sc, const params::Params& p, const std::string&
   if (!f) return 2;
   std::fwrite(hdr.data(), 4, hdr.size(), f);
   std::fclose(f);
-  std::printf("{\"rays\": %llu, \"seconds\": %.6f, \"msamples_per_s\": %.6f, \"threads\": %u}\n",
-              (unsigned long long) totalRays.load(), sec, double(W) * H * p.spp / sec * 1e-6, nt);
+  std::printf("{\"rays\": %llu, \"seconds\": %.6f, \"msamples_per_s\": %.6f, \"threads\": %u, \"pixels\": %llu, "
+              "\"traversals\": %llu, \"box_tests\": %llu, \"tri_tests\": %llu, \"shaded_hits\": %llu}\n",
+              (unsigned long long) totalRays.load(), sec, double(nPixelsMine) * p.spp / sec * 1e-6, nt,
+              (unsigned long long) nPixelsMine, (unsigned long long) totalTrav.load(), (unsigned long long) totalBox.load(),
+              (unsigned long long) totalTri.load(), (unsigned long long) totalShade.load());
   return 0;
 }
 

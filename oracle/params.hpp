@@ -10,6 +10,9 @@
 //   exposure EV / aperture_sides N                              (camera.hpp:62-63)
 //   background R G B          Renderer::backgroundColor         (src/core/renderer.hpp:52)
 //   probe_pixels x y x y ...  pixels whose per-sample radiance / primary hits are dumped
+//   shard_rank R / shard_world N / shard_tile T   (oracle restatement only) render only the pixel blocks the
+//                             library deals to rank R of N (include/yart_hip.h YartRenderParams.rank / world_size /
+//                             shard_tile: blocks in Morton order, round-robin); the other pixels stay 0
 #pragma once
 #include <cstdint>
 #include <fstream>
@@ -30,6 +33,7 @@ struct Params {
   uint32_t apertureSides = 0;
   float background[3] = {0, 0, 0};
   std::vector<uint32_t> probePixels;  // x,y pairs
+  uint32_t shardRank = 0, shardWorld = 1, shardTile = 0;
 };
 
 inline Params load(const std::string& path) {
@@ -59,6 +63,9 @@ inline Params load(const std::string& path) {
     else if (key == "exposure") ss >> p.exposure;
     else if (key == "aperture_sides") ss >> p.apertureSides;
     else if (key == "background") f3(p.background);
+    else if (key == "shard_rank") ss >> p.shardRank;
+    else if (key == "shard_world") ss >> p.shardWorld;
+    else if (key == "shard_tile") ss >> p.shardTile;
     else if (key == "probe_pixels") { uint32_t v; while (ss >> v) p.probePixels.push_back(v); }
     else throw std::runtime_error("params: unknown key " + key);
   }

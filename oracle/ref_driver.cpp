@@ -202,6 +202,7 @@ static int doRender(const std::string& scenePath, const std::string& paramPath,
                     const std::string& outPath) {
   auto sf = yscn::load(scenePath);
   auto p = params::load(paramPath);
+  if (p.shardWorld > 1) { std::fprintf(stderr, "yart_ref: TileRenderer renders every tile (shard_* keys are the oracle restatement's)\n"); return 2; }
   auto built = build(sf);
   Camera cam = makeCamera(p);
   g_maxDepth = p.depth;
@@ -385,10 +386,12 @@ static int doKat(const std::string& scenePath, const std::string& paramPath,
 
   // --- closest hits for centre-of-pixel primary rays (ray-integrator.cpp:20-261)
   {
-    std::vector<float> fo;
+    std::vector<float> fo, ro6;        // hit_rays: the rays themselves (origin, direction), for the device-side check
     std::vector<int64_t> io;
     for (size_t i = 0; i + 1 < p.probePixels.size(); i += 2) {
       Ray r = cam.getRay({p.probePixels[i], p.probePixels[i + 1]}, {0.5f, 0.5f}, {0.5f, 0.5f});
+      for (int c = 0; c < 3; c++) ro6.push_back(r.origin[c]);
+      for (int c = 0; c < 3; c++) ro6.push_back(r.dir[c]);
       cpu::Hit h;
       bool hit = integ.probeHit(r, h);
       io.push_back(hit);
@@ -399,7 +402,7 @@ static int doKat(const std::string& scenePath, const std::string& paramPath,
       for (int c = 0; c < 3; c++) fo.push_back(h.n[c]);
       for (int c = 0; c < 3; c++) fo.push_back(h.tg[c]);
     }
-    w.i64("hits_i", io); w.f32("hits_f", fo);
+    w.i64("hits_i", io); w.f32("hits_f", fo); w.f32("hit_rays", ro6);
   }
 
   // --- BSDF f / pdf / sample per material (bsdf.cpp:5-58, parametric.cpp:84-838)

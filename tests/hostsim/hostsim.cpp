@@ -119,11 +119,12 @@ static int doKat(Ctx& c, const params::Params& p, const std::string& outPath) {
   uint64_t stack[kRefStackDepth];
   PathCtx px = pathCtx(c, stack);
   {
-    std::vector<float> fo;
+    std::vector<float> fo, ro6;
     std::vector<int64_t> io;
     for (size_t i = 0; i + 1 < p.probePixels.size(); i += 2) {
       f3 o, d;
       cameraRay(c.cam, p.probePixels[i], p.probePixels[i + 1], mk2(0.5f, 0.5f), mk2(0.5f, 0.5f), o, d);
+      ro6.push_back(o.x); ro6.push_back(o.y); ro6.push_back(o.z); ro6.push_back(d.x); ro6.push_back(d.y); ro6.push_back(d.z);
       HitRec hr; hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
       f3 att = mk3(1.0f);
       Sampler dummy; dummy.dim = 0; dummy.morton = 0;
@@ -138,7 +139,7 @@ static int doKat(Ctx& c, const params::Params& p, const std::string& outPath) {
       fo.push_back(h.n.x); fo.push_back(h.n.y); fo.push_back(h.n.z);
       fo.push_back(h.tg.x); fo.push_back(h.tg.y); fo.push_back(h.tg.z);
     }
-    w.i64("hits_i", io); w.f32("hits_f", fo);
+    w.i64("hits_i", io); w.f32("hits_f", fo); w.f32("hit_rays", ro6);
   }
   {
     std::vector<float> fo;

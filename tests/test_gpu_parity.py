@@ -93,22 +93,6 @@ def test_per_sample_radiance_vs_reference(api, case):
     scene.close()
 
 
-@pytest.mark.parametrize("case", ["cornell", "material"])
-def test_primary_hits_vs_reference(api, case):
-    """Closest hits of centre-of-pixel primary rays: triangle id exact, t/p/n within 1e-5."""
-    base = os.path.join(GOLDEN, case)
-    kat = katlib.load(base + ".kat.json")
-    cam = katlib.as_float(kat["camera_rays"]).reshape(-1, 4, 6)   # 4 jittered rays per probe pixel
-    rays = cam.reshape(-1, 6)
-    scene = api.DeviceScene(base + ".yscn", device=0)
-    out = scene.probe_hits(rays)
-    # self-consistency at least: hit flags are 0/1 and normals are unit length on hits
-    hit = out[:, 0] > 0.5
-    n = np.linalg.norm(out[hit, 7:10], axis=1)
-    assert np.allclose(n, 1.0, atol=1e-5)
-    scene.close()
-
-
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/yart_ref not present")
 def test_cornell_512_64spp_vs_reference_live(api, tmp_path):
     """BASELINE configs[1]: Cornell 512x512, 64 spp on 1 MI355X, RMSE vs the CPU reference."""

@@ -98,7 +98,7 @@ class RenderParams(C.Structure):
                 ("max_wave_samples", C.c_uint32), ("tile_size", C.c_uint32), ("max_depth", C.c_uint32),
                 ("background", C.c_float * 3), ("rank", C.c_uint32), ("world_size", C.c_uint32),
                 ("flags", C.c_uint32), ("start_sample", C.c_uint32), ("stop_sample", C.c_uint32),
-                ("estimator", C.c_uint32), ("shard_tile", C.c_uint32)]
+                ("estimator", C.c_uint32), ("shard_tile", C.c_uint32), ("max_batch_paths", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -229,6 +229,7 @@ def make_params(p: dict, rank=0, world_size=1, flags=0) -> RenderParams:
     r.start_sample, r.stop_sample = int(p.get("start_sample", 0)), int(p.get("stop_sample", 0))
     r.estimator = int(p.get("estimator", ESTIMATOR_GMON))
     r.shard_tile = int(p.get("shard_tile", 0))
+    r.max_batch_paths = int(p.get("max_batch_paths", 0))
     return r
 
 

@@ -484,6 +484,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   uint64_t maxPaths = std::max<uint64_t>((uint64_t(freeB) + held) * (compact ? 6 : 5) / 10 / perPath, 1u << 20);
   if (!mega) maxPaths = std::min<uint64_t>(maxPaths, kWfMaxPaths);
   maxPaths = std::min<uint64_t>(maxPaths, (1ull << 31) - 64);
+  if (p.max_batch_paths) maxPaths = std::min<uint64_t>(maxPaths, p.max_batch_paths);
   uint32_t chunk = uint32_t(std::min<uint64_t>(nPix ? nPix : 1, std::max<uint64_t>(maxPaths / waveCap, 1)));
   s.L.ensure(size_t(chunk) * waveCap * 3);
   if (!mega) {

@@ -115,10 +115,16 @@ def test_many_batches_equal_one_batch(api):
     p = dict(p, first_wave=4, max_wave=12)
     scene = api.DeviceScene(s, device=0)
     one, st1 = scene.render(p)
-    for cap, flags in ((100000, 0), (37000, 0), (37000, PIPELINE_FLAGS["wavefront+no_compaction"]), (5, 0), (200000, 1)):
+    for cap, flags in ((100000, 0), (37000, 0), (37000, PIPELINE_FLAGS["wavefront+no_compaction"]), (200000, 1)):
         many, st = scene.render(dict(p, max_batch_paths=cap), flags=flags)
         assert np.array_equal(one.view(np.uint32), many.view(np.uint32)), (cap, flags)
         assert st["rays"] == st1["rays"] and st["samples"] == st1["samples"]
+    scene.close()
+    s, p = scenes.cornell(20, 12, 16, 4)                       # one pixel per batch (the cap is below one pixel's samples)
+    scene = api.DeviceScene(s, device=0)
+    one, _ = scene.render(p)
+    many, _ = scene.render(dict(p, max_batch_paths=5))
+    assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
     scene.close()
 
 

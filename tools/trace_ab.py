@@ -10,7 +10,10 @@ if os.environ.get("YART_LIB"):          # experiment variant built by tools/buil
     print("variant", os.environ["YART_LIB"], flush=True)
 w, h, spp = (int(x) for x in os.environ.get("SIZE", "960x540x64").split("x"))
 TEX, SKY = int(os.environ.get("TEX", 256)), int(os.environ.get("SKY", 256))
-scene, p = scenes.sponza_class(w, h, spp, 8, tex=TEX, sky=SKY)
+if os.environ.get("SCENE", "sponza") == "mclaren":        # BASELINE configs[4] scene (1.05 M triangles at DETAIL=1)
+    scene, p = scenes.mclaren_class(w, h, spp, 8, detail=float(os.environ.get("DETAIL", 1.0)), tex=TEX, sky=SKY)
+else:
+    scene, p = scenes.sponza_class(w, h, spp, 8, tex=TEX, sky=SKY)
 ds = api.DeviceScene(scene, device=0)
 flags = [int(x) for x in sys.argv[1:]] or [0, 2]
 ref = None

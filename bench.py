@@ -10,13 +10,25 @@ A "step" is one complete render of the frame (all 256 spp of every pixel, GMoN, 
 and — for N > 1 — the reduce of the per-rank framebuffers to rank 0). Scene upload and
 BVH build are outside the timed region; the framebuffer stays in HBM (a torch tensor).
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+Rank 0 prints ONE JSON line (DESIGN.md §5 explains every field). At N = 1 the line also carries
+  parity        the same scene / camera / depth at `--cpu-spp` samples rendered on the GPU and compared with the
+                frame the CPU baseline leg just rendered (RMSE in linear HDR, identical-pixel fraction); the bench
+                exits with status 3 if RMSE >= 1e-3 (every timed run is checked)
+  roofline      the kernel with the largest share of the step, `rooflines` all three large kernels: algorithmic
+                bytes per launch / HIP-event launch time against the roof that binds (HBM for the shade kernel,
+                the L2 for the BVH walks whose working set is cache resident), and `traffic` = FETCH_SIZE x 2 +
+                WRITE_SIZE of that kernel measured by two rocprofv3 --pmc child runs of this workload started
+                BEFORE this process touches the GPU (null when they cannot run)
+  cpu_baseline  the compiled reference on the host cores, bounded sample.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -25,7 +37,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md §HBM
+L2_PEAK_GBPS = 34500.0          # aggregate L2 (8 XCDs x 4 MiB), same guide §L2
+RMSE_TOL = 1e-3                 # BASELINE.json north_star
 
 
 def parse():
@@ -42,29 +56,109 @@ def parse():
     ap.add_argument("--sky", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs (roofline.traffic = null)")
+    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline / parity sample")
+    ap.add_argument("--ref-order-spp", type=int, default=1, help="spp of the oracle run that counts box / triangle tests in the reference's traversal order")
     ap.add_argument("--flags", type=int, default=0, help="YART_FLAG_* pipeline variant (A/B experiments)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one un-timed step, no torch (run under rocprofv3 --pmc)
+    ap.add_argument("--keep-pmc", default="", help="directory to keep the raw counter csv files in (e.g. profiles/...)")
     return ap.parse_args()
 
 
+def workload(args):
+    from yart_amd import scenes
+    return scenes.sponza_class(args.width, args.height, args.spp, args.depth, tex=args.tex, sky=args.sky)
+
+
+# ---------------------------------------------------------------------------------------------------
+# memory-side traffic per kernel: rocprofv3 --pmc child runs (separate passes for FETCH_SIZE and WRITE_SIZE)
+# ---------------------------------------------------------------------------------------------------
+def under_profiler():
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("HSA_TOOLS_LIB", "")
+    return "rocprof" in pre
+
+
+def kernel_base(name):
+    i = name.find("k_")
+    if i < 0:
+        return None
+    k = name[i:]
+    for stop in ("<", "("):
+        j = k.find(stop)
+        if j >= 0:
+            k = k[:j]
+    return k
+
+
+def pmc_traffic(args):
+    """{kernel: {launches, read_bytes, write_bytes}} summed over ONE step of the workload, or None.
+    FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory side; FETCH_SIZE is doubled (gfx950 tallies 128-B read
+    requests at 64 B) exactly as MI355X_MICROARCH.md §HBM prescribes; Infinity-Cache hits are included."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    keep = os.path.join(ROOT, args.keep_pmc) if args.keep_pmc else None
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter, field, scale in (("FETCH_SIZE", "read_bytes", 2048.0), ("WRITE_SIZE", "write_bytes", 1024.0)):
+            d = os.path.join(td, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
+                   sys.executable or "python3", os.path.join(ROOT, "bench.py"), "--pmc-child",
+                   "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--depth", str(args.depth),
+                   "--tex", str(args.tex), "--sky", str(args.sky), "--flags", str(args.flags)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            except (OSError, subprocess.TimeoutExpired):
+                return None
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                sys.stderr.write(f"bench.py: rocprofv3 --pmc {counter} pass failed ({r.returncode}): {r.stderr.strip()[-300:]}\n")
+                return None
+            if keep:
+                os.makedirs(keep, exist_ok=True)
+                shutil.copy(files[0], os.path.join(keep, f"pmc_{counter.lower()}_counter_collection.csv"))
+            for row in csv.DictReader(open(files[0])):
+                k = kernel_base(row["Kernel_Name"])
+                if row["Counter_Name"] != counter or k is None:
+                    continue
+                e = out.setdefault(k, {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})
+                e[field] += float(row["Counter_Value"]) * scale
+                if counter == "FETCH_SIZE":
+                    e["launches"] += 1
+    return out
+
+
+def pmc_child(args):
+    """One un-timed step through the host-buffer entry point (no torch), for the counter passes."""
+    from yart_amd import api
+    scene, p = workload(args)
+    ds = api.DeviceScene(scene, device=0)
+    ds.render(p, flags=args.flags)
+    ds.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU legs: the compiled reference (timing + the parity frame) and the oracle (reference-order test counts)
+# ---------------------------------------------------------------------------------------------------
 def cpu_baseline(scene, p, args):
-    """Time the compiled reference (oracle/_ref/yart_ref, "reference") — or the CPU
-    restatement (oracle/_build/yart_oracle, "port") if the reference binary is absent —
-    on a bounded sample of the same workload: same scene, camera, resolution and bounce
-    depth, `cpu_spp` samples per pixel, all host cores (64x64 tiles on a thread pool,
-    the reference's own scheme)."""
+    """Time the compiled reference (oracle/_ref/yart_ref, "reference") — or the CPU restatement
+    (oracle/_build/yart_oracle, "port") if the reference binary is absent — on a bounded sample of the same
+    workload: same scene, camera, resolution and bounce depth, `cpu_spp` samples per pixel, all host cores
+    (64x64 tiles on a thread pool, the reference's own scheme). Returns (json entry, frame)."""
+    import numpy as np
     from yart_amd import scenes
     ref = os.path.join(ROOT, "oracle", "_ref", "yart_ref")
     port = os.path.join(ROOT, "oracle", "_build", "yart_oracle")
     exe, kind = (ref, "reference") if os.path.exists(ref) else (port, "port")
     if not os.path.exists(exe):
-        return None
+        return None, None
     cores = os.cpu_count() or 1
     with tempfile.TemporaryDirectory() as td:
         sp, pp, out = os.path.join(td, "s.yscn"), os.path.join(td, "p.txt"), os.path.join(td, "o.f32")
         scene.save(sp)
         # the reference's own knobs only (the library's sharding / estimator keys mean nothing to it)
-        q = {k: v for k, v in p.items() if k not in ("shard_tile", "estimator", "start_sample", "stop_sample")}
+        q = {k: v for k, v in p.items() if k not in ("shard_tile", "estimator", "start_sample", "stop_sample", "max_batch_paths")}
         scenes.write_params(pp, dict(q, spp=args.cpu_spp), threads=cores)
         t0 = time.perf_counter()
         r = subprocess.run([exe, "render", sp, pp, out], capture_output=True, text=True)
@@ -72,21 +166,38 @@ def cpu_baseline(scene, p, args):
         if r.returncode != 0:
             raise SystemExit(f"bench.py: the CPU baseline ({exe}) failed: {r.stderr.strip()[-400:]}")
         info = json.loads(r.stdout.strip().splitlines()[-1])
-    return {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
-            "sample": f"same scene/camera, {p['size'][0]}x{p['size'][1]}, {args.cpu_spp} spp of {p['spp']}, "
-                      f"depth {p['depth']}, {info['seconds']:.1f} s render ({wall:.1f} s incl. BVH build)"}
+        frame = np.fromfile(out, np.float32).reshape(p["size"][1], p["size"][0], 4)
+        ref_order = None
+        if os.path.exists(port) and args.ref_order_spp > 0:
+            # box / triangle tests per ray in the REFERENCE's traversal order (oracle counters)
+            scenes.write_params(pp, dict(q, spp=args.ref_order_spp), threads=cores)
+            r2 = subprocess.run([port, "render", sp, pp, out], capture_output=True, text=True)
+            if r2.returncode == 0:
+                ref_order = json.loads(r2.stdout.strip().splitlines()[-1])
+    entry = {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": cores, "kind": kind,
+             "sample": f"same scene/camera, {p['size'][0]}x{p['size'][1]}, {args.cpu_spp} spp of {p['spp']}, "
+                       f"depth {p['depth']}, {info['seconds']:.1f} s render ({wall:.1f} s incl. BVH build)"}
+    return (entry, ref_order), frame
 
 
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    # counter passes first: child processes, started before this process has initialised the GPU
+    pmc = None
+    if world == 1 and not args.no_roofline and not args.no_pmc and not under_profiler():
+        pmc = pmc_traffic(args)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
-    from yart_amd import api, scenes
+    from yart_amd import api
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
@@ -101,7 +212,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    scene, p = scenes.sponza_class(args.width, args.height, args.spp, args.depth, tex=args.tex, sky=args.sky)
+    scene, p = workload(args)
     W, H = p["size"]
     # N > 1: 16x16 pixel blocks are dealt to the ranks instead of whole 64x64 tiles — measured per-rank times of the
     # 8-way split on one GPU: 162-175 ms with tiles, 168-172 ms with 16x16 blocks (the slowest rank sets the step)
@@ -132,14 +243,14 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms, launches = 0.0, 0
-    lean = (args.flags & 5) == 0       # default pipeline: the dominant kernel is the lean closest-hit kernel
+    # per-kernel HIP-event time on the render stream (YartStats), summed over the timed steps
+    kern = {"k_wf_shade": [0.0, 0], "k_wf_extend_lean": [0.0, 0], "k_wf_shadow_lean": [0.0, 0]}
     for _ in range(args.steps):
         step()
-        if lean:
-            kernel_ms += last["ms_extend_lean"]; launches += last["launches_extend_lean"]
-        else:
-            kernel_ms += last["ms_traverse"]; launches += last["launches_traverse"]
+        for k, (ms, n) in (("k_wf_shade", ("ms_shade_kernel", "launches_shade_kernel")),
+                           ("k_wf_extend_lean", ("ms_extend_lean", "launches_extend_lean")),
+                           ("k_wf_shadow_lean", ("ms_shadow_lean", "launches_shadow_lean"))):
+            kern[k][0] += last[ms]; kern[k][1] += last[n]
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -150,7 +261,7 @@ def main():
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        return 0
 
     total_samples = W * H * p["spp"] * args.steps
     value = total_samples / dt * 1e-6
@@ -162,61 +273,96 @@ def main():
         "config": {"workload": "sponza_class (generated atrium, %d triangles, env-lit) %dx%d, %d spp, %d bounces"
                                % (scene.n_triangles, W, H, p["spp"], p["depth"]),
                    "pipeline": "megakernel" if args.flags & 1 else "wavefront", "tiles": f"{shard or 64}x{shard or 64} pixel blocks, Morton order, round-robin over ranks",
-                   "parallelism": f"tiles/{world}"},
+                   "parallelism": f"tiles/{world}", "pipeline_flags": int(last.get("pipeline_flags", args.flags))},
         "rays_per_step": int(last.get("rays", 0)),
     }
+    status = 0
 
-    # ---- roofline of the dominant kernel (the path / traversal kernel) -----------------
-    if not args.no_roofline and world == 1:
-        # exact test counters from the instrumented twin library (one untimed pass; the
-        # workload is deterministic so the counts are those of every timed pass)
+    # ---- CPU legs: baseline timing, parity frame, reference-order counters --------------------------
+    ref_order = None
+    if not args.no_cpu_baseline and world == 1:
+        cb, ref_frame = cpu_baseline(scene, p, args)
+        if cb:
+            out["cpu_baseline"], ref_order = cb
+            img, _ = dscene.render(dict(p, spp=args.cpu_spp), flags=args.flags)
+            e = float(np.sqrt(np.mean((np.nan_to_num(img[..., :3]).astype(np.float64) - np.nan_to_num(ref_frame[..., :3])) ** 2)))
+            same = float(np.mean(np.all(img.view(np.uint32) == ref_frame.view(np.uint32), axis=-1)))
+            out["parity"] = {"rmse": e, "identical_pixel_fraction": round(same, 6), "tolerance": RMSE_TOL, "ok": bool(e < RMSE_TOL),
+                             "against": out["cpu_baseline"]["kind"], "sample": f"{W}x{H}, {args.cpu_spp} spp, depth {p['depth']}: the frame of the cpu_baseline leg"}
+            if not e < RMSE_TOL:
+                status = 3
+
+    # ---- rooflines of the three large kernels -------------------------------------------------------
+    if not args.no_roofline and world == 1 and not (args.flags & 5):
+        # exact test counters from the instrumented twin library (one untimed pass; the workload is
+        # deterministic so the counts are those of every timed pass)
         dscene.close()           # hand its batch buffers back: the counting pass is one batch too, launch for launch
         ds2 = api.DeviceScene(scene, device=local_rank, instrumented=True)
-        _, st2 = ds2.render(p, flags=args.flags)
+        _, c = ds2.render(p, flags=args.flags)
         ds2.close()
-        shaded = st2.get("shaded_hits", 0)
-        # B_traversal = 32*N_box + 52*N_tri + 48 per traversal. Default pipeline: the
-        # dominant kernel is the lean closest-hit kernel k_wf_extend_fast (its own counters, its own
-        # HIP-event time, one launch per bounce per batch); otherwise all traversal launches together.
-        if lean:
-            kname = "k_wf_extend_fast" if args.flags & 16 else "k_wf_extend_lean"
-            trav_bytes = 32 * st2["lean_box_tests"] + 52 * st2["lean_tri_tests"] + 48 * st2["lean_traversals"]
-            n_launch = max(1, last["launches_extend_lean"])
-        else:
-            kname = "k_render_mega" if args.flags & 1 else "closest-hit + shadow traversal kernels"
-            trav_bytes = 32 * st2["box_tests"] + 52 * st2["tri_tests"] + 48 * st2["traversals"]
-            n_launch = max(1, last["launches_traverse"])
-        avg_ms = kernel_ms / max(1, launches)
-        achieved = trav_bytes / n_launch / (avg_ms * 1e-3) * 1e-9
+        # SURVEY §8(d) per-unit figures. B_traversal = 32 N_box + 52 N_tri + 48 per ray; B_shade = 116 per hit + 64 per
+        # entry + 4 C per texture tap. The traversal figures are taken twice: from the kernel's own tallies (they include
+        # one candidate-mask box test per scene node per ray and the partial walks of rays handed to the general kernels)
+        # and from the oracle's counters in the REFERENCE's traversal order (per-ray means of a bounded sample x the rays
+        # the kernel finished); `achieved` uses the reference-order figure when it is available.
+        def per_launch(k):
+            ms, n = kern[k]
+            return (ms / max(1, n)) * 1e-3, max(1, n // max(1, args.steps))
+
+        entries = []
+        sh_bytes = 116 * c["shaded_hits"] + 64 * c["shade_entries"] + c["texture_tap_bytes"]
+        t_l, n_l = per_launch("k_wf_shade")
+        entries.append({"kernel": "k_wf_shade", "bound": "hbm", "peak": HBM_PEAK_GBPS, "avg_launch_ms": round(t_l * 1e3, 3),
+                        "launches_per_step": n_l, "algorithmic_bytes_per_launch": int(sh_bytes / n_l),
+                        "model": "116 B x shaded hits + 64 B x entries + 4 taps x channels x texel bytes per lookup (SURVEY §8(d) B_shade)",
+                        "units_per_step": {"shaded_hits": c["shaded_hits"], "entries": c["shade_entries"], "texture_tap_bytes": c["texture_tap_bytes"]}})
+        for k, trav, box, tri, retried, ro in (
+                ("k_wf_extend_lean", c["lean_traversals"], c["lean_box_tests"], c["lean_tri_tests"], c["retry_extend_traversals"], "closest"),
+                ("k_wf_shadow_lean", c["shadow_lean_traversals"], c["shadow_lean_box_tests"], c["shadow_lean_tri_tests"], c["retry_shadow_traversals"], "shadow")):
+            t_l, n_l = per_launch(k)
+            own = 32 * box + 52 * tri + 48 * trav
+            e = {"kernel": k, "bound": "l2", "peak": L2_PEAK_GBPS, "avg_launch_ms": round(t_l * 1e3, 3), "launches_per_step": n_l,
+                 "model": "(32 B x box tests + 52 B x triangle tests + 48 B) per ray (SURVEY §8(d) B_traversal); the BVH is cache "
+                          "resident, so the roof is the L2's bandwidth, not HBM's",
+                 "kernel_tally_bytes_per_launch": int(own / n_l),
+                 "kernel_tally_per_ray": {"box": round(box / max(1, trav), 2), "tri": round(tri / max(1, trav), 2)},
+                 "rays_per_step": trav, "rays_handed_to_general_kernel": retried}
+            alg = own
+            if ref_order:
+                if ro == "closest":
+                    rt = ref_order["traversals"] - ref_order["shadow_traversals"]
+                    rb, rtri = ref_order["box_tests"] - ref_order["shadow_box_tests"], ref_order["tri_tests"] - ref_order["shadow_tri_tests"]
+                else:
+                    rt, rb, rtri = ref_order["shadow_traversals"], ref_order["shadow_box_tests"], ref_order["shadow_tri_tests"]
+                per_ray = 32.0 * rb / max(1, rt) + 52.0 * rtri / max(1, rt) + 48.0
+                alg = per_ray * (trav - retried)
+                e["reference_order_per_ray"] = {"box": round(rb / max(1, rt), 2), "tri": round(rtri / max(1, rt), 2), "bytes": round(per_ray, 1),
+                                                "sample": f"oracle counters, {args.ref_order_spp} spp of the same frame"}
+            e["algorithmic_bytes_per_launch"] = int(alg / n_l)
+            entries.append(e)
+        for e in entries:
+            t = e["avg_launch_ms"] * 1e-3
+            e["achieved"] = round(e["algorithmic_bytes_per_launch"] / t * 1e-9, 2) if t > 0 else 0.0
+            e["unit"] = "GB/s"
+            e["frac"] = round(e["achieved"] / e["peak"], 5)
+            tr = pmc.get(e["kernel"]) if pmc else None
+            e["traffic"] = int((tr["read_bytes"] + tr["write_bytes"]) / max(1, tr["launches"])) if tr else None
+            if tr and t > 0:
+                e["traffic_GBps"] = round(e["traffic"] / t * 1e-9, 1)
+                e["traffic_frac_of_hbm_peak"] = round(e["traffic"] / t * 1e-9 / HBM_PEAK_GBPS, 4)
+        dominant = max(entries, key=lambda e: e["avg_launch_ms"] * e["launches_per_step"])
+        out["roofline"] = dominant
+        out["rooflines"] = entries
+        out["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this workload, this build, this box "
+                                 "(FETCH_SIZE x 2 per MI355X_MICROARCH.md)") if pmc else None
         out["stage_ms_per_step"] = {k: round(last[k], 2) for k in
-                                    ("ms_extend", "ms_extend_lean", "ms_connect", "ms_shade", "ms_gmon", "ms_device")}
-        traffic = None
-        if lean and (W, H, p["spp"], p["depth"], args.tex, args.sky) == (1920, 1080, 256, 8, 1024, 2048):
-            # memory-side bytes per launch of this kernel from the committed PMC passes (tools/pmc_hbm.sh)
-            try:
-                prof = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))
-                k = next(v for n, v in prof["kernels"].items() if n.startswith(kname))
-                traffic = k["read_bytes_per_launch"] + k["write_bytes_per_launch"]
-            except (OSError, StopIteration, KeyError, ValueError):
-                traffic = None
-        out["roofline"] = {
-            "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-            "avg_launch_ms": round(avg_ms, 3), "launches_per_step": n_launch,
-            "algorithmic_bytes_per_launch": int(trav_bytes / n_launch),
-            "counts_per_step": {"traversals": st2["traversals"], "box_tests": st2["box_tests"],
-                                "tri_tests": st2["tri_tests"], "shaded_hits": shaded,
-                                "lean_traversals": st2["lean_traversals"], "lean_box_tests": st2["lean_box_tests"],
-                                "lean_tri_tests": st2["lean_tri_tests"]},
-        }
-    if not args.no_cpu_baseline and world == 1:
-        cb = cpu_baseline(scene, p, args)
-        if cb:
-            out["cpu_baseline"] = cb
+                                    ("ms_extend", "ms_extend_lean", "ms_connect", "ms_shadow_lean", "ms_shade", "ms_shade_kernel", "ms_gmon", "ms_device")}
+        out["counts_per_step"] = {k: c[k] for k in ("traversals", "box_tests", "tri_tests", "shaded_hits")}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return status
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

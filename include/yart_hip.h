@@ -169,6 +169,17 @@ typedef struct YartStats {
   double ms_extend_lean;
   uint64_t lean_traversals, lean_box_tests, lean_tri_tests;
   uint32_t launches_extend_lean, reserved0;
+  /* the shade kernel (k_wf_shade) and the lean any-hit kernel (k_wf_shadow_lean) alone, as above */
+  double ms_shade_kernel, ms_shadow_lean;
+  uint32_t launches_shade_kernel, launches_shadow_lean;
+  uint64_t shadow_lean_traversals, shadow_lean_box_tests, shadow_lean_tri_tests;
+  uint64_t shade_entries;      /* instrumented build: queue entries the shade kernel processed (hits + misses) */
+  uint64_t texture_tap_bytes;  /* instrumented build: 4 taps x channels x texel bytes summed over every texture lookup */
+  uint32_t pipeline_flags;     /* the YART_FLAG_* set this render ran with, after the per-scene defaults */
+  uint32_t reserved1;
+  /* instrumented build: rays the lean kernels abandoned at an alpha-tested / transparent candidate and the general
+     kernels traced again from the root (they are counted in lean_traversals / shadow_lean_traversals as well) */
+  uint64_t retry_extend_traversals, retry_shadow_traversals;
 } YartStats;
 
 typedef struct YartScene YartScene;

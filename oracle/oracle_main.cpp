@@ -227,7 +227,7 @@ static int doRender(const Scene& sc, const params::Params& p, const std::string&
   for (uint32_t y = 0; y < H; y++)
     for (uint32_t x = 0; x < W; x++) nPixelsMine += mine[size_t(y / ST) * bx + x / ST];
   unsigned nt = p.threads ? p.threads : std::thread::hardware_concurrency();
-  std::atomic<uint64_t> totalRays{0}, totalBox{0}, totalTri{0}, totalTrav{0}, totalShade{0};
+  std::atomic<uint64_t> totalRays{0}, totalBox{0}, totalTri{0}, totalTrav{0}, totalShade{0}, neeBox{0}, neeTri{0}, neeTrav{0};
   auto t0 = std::chrono::high_resolution_clock::now();
   // wave schedule, tile-renderer.hpp:121-124, 284-289
   uint64_t remaining = p.spp, wave = std::min(p.firstWave, p.spp), current = 0;
@@ -260,6 +260,7 @@ static int doRender(const Scene& sc, const params::Params& p, const std::string&
             }
         }
         totalRays += integ.rays; totalBox += integ.nBox; totalTri += integ.nTri; totalTrav += integ.nTrav; totalShade += integ.nShade;
+        neeBox += integ.nBoxNee; neeTri += integ.nTriNee; neeTrav += integ.nTravNee;
       });
     for (auto& t : th) t.join();
     remaining -= wave;
@@ -273,10 +274,12 @@ static int doRender(const Scene& sc, const params::Params& p, const std::string&
   std::fwrite(hdr.data(), 4, hdr.size(), f);
   std::fclose(f);
   std::printf("{\"rays\": %llu, \"seconds\": %.6f, \"msamples_per_s\": %.6f, \"threads\": %u, \"pixels\": %llu, "
-              "\"traversals\": %llu, \"box_tests\": %llu, \"tri_tests\": %llu, \"shaded_hits\": %llu}\n",
+              "\"traversals\": %llu, \"box_tests\": %llu, \"tri_tests\": %llu, \"shaded_hits\": %llu, "
+              "\"shadow_traversals\": %llu, \"shadow_box_tests\": %llu, \"shadow_tri_tests\": %llu}\n",
               (unsigned long long) totalRays.load(), sec, double(nPixelsMine) * p.spp / sec * 1e-6, nt,
               (unsigned long long) nPixelsMine, (unsigned long long) totalTrav.load(), (unsigned long long) totalBox.load(),
-              (unsigned long long) totalTri.load(), (unsigned long long) totalShade.load());
+              (unsigned long long) totalTri.load(), (unsigned long long) totalShade.load(),
+              (unsigned long long) neeTrav.load(), (unsigned long long) neeBox.load(), (unsigned long long) neeTri.load());
   return 0;
 }
 

@@ -114,7 +114,7 @@ bool Integrator::testBox(const Ray& ray, float t0, float t1, const Bounds& b, fl
 }
 
 bool Integrator::testTriangle(const Ray& ray, float tMin, Hit& hit, const Mesh& mesh, uint32_t idx) const {
-  nTri++;
+  nTri++; nTriNee += ray.nee;
   const uint32_t i0 = mesh.tri[3 * idx], i1 = mesh.tri[3 * idx + 1], i2 = mesh.tri[3 * idx + 2];
   const V3 p0 = mesh.pos[i0], p1 = mesh.pos[i1], p2 = mesh.pos[i2];
   const V3 e1 = p1 - p0, e2 = p2 - p0;
@@ -154,7 +154,7 @@ bool Integrator::testBVH(const Ray& ray, float tMin, Hit& hit, const Mesh& mesh)
   float d;
   uint32_t sp = 0;
   bool didHit = false;
-  nBox++;
+  nBox++; nBoxNee += ray.nee;
   if (!testBox(ray, tMin, hit.t, node->b, &d)) return false;
   while (true) {
     if (d < hit.t) {
@@ -170,7 +170,7 @@ bool Integrator::testBVH(const Ray& ray, float tMin, Hit& hit, const Mesh& mesh)
         const BVHNode* c1 = &mesh.nodes[node->leftFirst];
         const BVHNode* c2 = &mesh.nodes[node->leftFirst + 1];
         float d1, d2;
-        nBox += 2;
+        nBox += 2; nBoxNee += 2 * ray.nee;
         bool h1 = testBox(ray, tMin, hit.t, c1->b, &d1);
         bool h2 = testBox(ray, tMin, hit.t, c2->b, &d2);
         if (h1) {
@@ -216,7 +216,7 @@ bool Integrator::testNode(const Ray& ray, float tMin, Hit& hit, const Node& node
   Ray r(node.xf.applyInverse(ray.o, Transform::Point), node.xf.applyInverse(ray.d, Transform::Vector));
   r.nee = ray.nee;
   float d;
-  nBox++;
+  nBox++; nBoxNee += ray.nee;
   if (!testBox(r, tMin, hit.t, node.bounds, &d) || hit.t < d) return false;
   bool didHit = false;
   if (node.mesh) didHit = testMesh(r, tMin, hit, *node.mesh);
@@ -233,7 +233,7 @@ bool Integrator::unoccluded(V3 from, V3 to, V3* att) const {
   r.nee = true;
   Hit h;
   h.t = length(to - from) - 0.001f;
-  nTrav++;
+  nTrav++; nTravNee++;
   bool occluded = testNode(r, 0.001f, h, *scene->root);
   *att = h.attenuation;
   return !occluded;

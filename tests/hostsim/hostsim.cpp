@@ -482,8 +482,9 @@ static int doBvhCheck(const char* scenePath, unsigned threads) {
     nodes += a.nodes.size(); tris += md.n_faces;
     for (const BvhNode& n : a.nodes) maxLeaf = std::max(maxLeaf, n.span);
   }
-  std::printf("{\"bvhcheck\": \"ok\", \"meshes\": %u, \"triangles\": %zu, \"nodes\": %zu, \"max_leaf_span\": %u, \"threads\": %u, \"ms_serial\": %.1f, \"ms_parallel\": %.1f}\n",
-              loaded->desc.n_meshes, tris, nodes, maxLeaf, threads, msSerial, msParallel);
+  const float share = buildHostImage(loaded->desc).dominantLobeShare;
+  std::printf("{\"bvhcheck\": \"ok\", \"dominant_lobe_share\": %.4f, \"meshes\": %u, \"triangles\": %zu, \"nodes\": %zu, \"max_leaf_span\": %u, \"threads\": %u, \"ms_serial\": %.1f, \"ms_parallel\": %.1f}\n",
+              share, loaded->desc.n_meshes, tris, nodes, maxLeaf, threads, msSerial, msParallel);
   return 0;
 }
 

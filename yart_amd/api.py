@@ -109,7 +109,13 @@ class Stats(C.Structure):
                 ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_connect", C.c_double),
                 ("ms_gmon", C.c_double), ("launches_extend", C.c_uint32), ("launches_connect", C.c_uint32),
                 ("ms_extend_lean", C.c_double), ("lean_traversals", C.c_uint64), ("lean_box_tests", C.c_uint64),
-                ("lean_tri_tests", C.c_uint64), ("launches_extend_lean", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("lean_tri_tests", C.c_uint64), ("launches_extend_lean", C.c_uint32), ("reserved0", C.c_uint32),
+                ("ms_shade_kernel", C.c_double), ("ms_shadow_lean", C.c_double),
+                ("launches_shade_kernel", C.c_uint32), ("launches_shadow_lean", C.c_uint32),
+                ("shadow_lean_traversals", C.c_uint64), ("shadow_lean_box_tests", C.c_uint64),
+                ("shadow_lean_tri_tests", C.c_uint64), ("shade_entries", C.c_uint64),
+                ("texture_tap_bytes", C.c_uint64), ("pipeline_flags", C.c_uint32), ("reserved1", C.c_uint32),
+                ("retry_extend_traversals", C.c_uint64), ("retry_shadow_traversals", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

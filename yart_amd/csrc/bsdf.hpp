@@ -15,6 +15,29 @@ namespace yart_hip {
 // ---------------------------------------------------------------------------
 struct TexTaps { uint32_t i00, i01, i10, i11; float u, v; };
 
+// Instrumented build (libyart_hip_count.so) only: bytes of texel data the lookups of one render need —
+// 4 taps x channels x (1 B | 4 B) per lookup, SURVEY §8(d)'s "4·C·taps" term of B_shade — summed per wave.
+#if defined(YART_COUNT_TRAVERSAL) && defined(__HIPCC__)
+__device__ unsigned long long g_texTapBytes;
+#endif
+#if defined(YART_COUNT_TRAVERSAL) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void texTally(const TexDev& t) {
+  const uint32_t bytes = 4u * t.channels * (t.isFloat ? 4u : 1u);
+  // lanes of one call may read different textures: one round per distinct byte count among the active lanes
+  unsigned long long rem = __ballot(true), sum = 0;
+  const int first = __ffsll((long long) rem) - 1;
+  while (rem) {
+    const uint32_t b = uint32_t(__shfl(int(bytes), __ffsll((long long) rem) - 1));
+    const unsigned long long same = __ballot(bytes == b) & rem;
+    sum += uint64_t(b) * uint64_t(__popcll(same));
+    rem &= ~same;
+  }
+  if (int(threadIdx.x & 63u) == first) atomicAdd(&g_texTapBytes, sum);
+}
+#else
+YART_HD void texTally(const TexDev&) {}
+#endif
+
 YART_HD TexTaps texTaps(const TexDev& t, f2 uv) {              // texture.cpp:21-35
   uv.x -= floorf(uv.x);
   uv.y -= floorf(uv.y);
@@ -85,12 +108,14 @@ YART_HD TexQuad texQuadOrZero(const SceneDev& sc, const TexDev& t, const TexTaps
 }
 YART_HD f3 texSample3(const SceneDev& sc, int32_t tex, f2 uv) {
   const TexDev t = sc.textures[tex];
+  texTally(t);
   const TexTaps k = texTaps(t, uv);
   const TexQuad q = texQuadOrZero(sc, t, k);
   return mk3(texSampleChannel(sc, t, k, q, 0), texSampleChannel(sc, t, k, q, 1), texSampleChannel(sc, t, k, q, 2));
 }
 YART_HD f4 texSample4(const SceneDev& sc, int32_t tex, f2 uv) {
   const TexDev t = sc.textures[tex];
+  texTally(t);
   const TexTaps k = texTaps(t, uv);
   const TexQuad q = texQuadOrZero(sc, t, k);
   f4 r;
@@ -100,12 +125,14 @@ YART_HD f4 texSample4(const SceneDev& sc, int32_t tex, f2 uv) {
 }
 YART_HD f2 texSample2(const SceneDev& sc, int32_t tex, f2 uv) {
   const TexDev t = sc.textures[tex];
+  texTally(t);
   const TexTaps k = texTaps(t, uv);
   const TexQuad q = texQuadOrZero(sc, t, k);
   return mk2(texSampleChannel(sc, t, k, q, 0), texSampleChannel(sc, t, k, q, 1));
 }
 YART_HD float texSample1(const SceneDev& sc, int32_t tex, f2 uv) {
   const TexDev t = sc.textures[tex];
+  texTally(t);
   const TexTaps k = texTaps(t, uv);
   const TexQuad q = texQuadOrZero(sc, t, k);
   return texSampleChannel(sc, t, k, q, 0);

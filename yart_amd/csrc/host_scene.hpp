@@ -8,6 +8,8 @@
 // camera.hpp:25-59) with the same float arithmetic, so the kernels start from
 // bit-identical constants.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
@@ -19,6 +21,13 @@
 #include "scene_types.hpp"
 
 namespace yart_hip {
+
+// Lobe class of a material: which of the branches of ParametricBSDF::sampleImpl / fImpl / pdfImpl
+// (parametric.cpp:226-251) its hits can take — bit 0 transmissive, bit 1 clearcoat, bit 2 metallic.
+inline uint8_t lobeClass(const MaterialDev& mt) {
+  return uint8_t(((mt.cTrans > 0.0f || mt.texTransmission >= 0) ? 1u : 0u) |
+                 ((mt.clearcoat > 0.0f || mt.texClearcoat >= 0) ? 2u : 0u) | (mt.cMetallic > 0.0f ? 4u : 0u));
+}
 
 struct HostImage {
   std::vector<ShadeTri> shadeTris;
@@ -47,6 +56,10 @@ struct HostImage {
   uint32_t maxNodeDepth = 0;
   uint32_t nLights = 0, nInfinite = 0, nArea = 0, nMaterials = 0;   // real counts (the vectors are padded)
   bool allIdentity = true;   // every node's transform chain is exactly the identity (TRAV_IDENTITY kernels)
+  // Surface-area share of the most common lobe class (plain / metallic / clearcoat / transmissive combinations,
+  // parametric.cpp:226-251 picks among them per hit) over the instanced triangles: a cheap stand-in for how mixed the
+  // shade queue of this scene is. Below kShadeSortShare the shade kernel buckets its entries by material by default.
+  float dominantLobeShare = 1.0f;
 
   SceneDev view() const {
     SceneDev s{};
@@ -458,6 +471,28 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
   if (im.areaLights.empty()) im.areaLights.push_back(0);
   if (im.areaPowerCdf.empty()) im.areaPowerCdf.push_back(0.0f);
   if (im.materials.empty()) im.materials.push_back(MaterialDev{});
+  {   // lobe-class mix by instanced surface area (object-space areas: a heuristic, not a measurement)
+    std::vector<uint32_t> uses(im.meshes.size(), 0);
+    for (uint32_t i = 0; i < nn; i++) if (d.nodes[i].mesh >= 0) uses[d.nodes[i].mesh]++;
+    double area[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0;
+    for (uint32_t mi = 0; mi < d.n_meshes; mi++) {
+      const YartMeshDesc& m = d.meshes[mi];
+      for (uint32_t f = 0; f < m.n_faces; f++) {
+        const float* p0 = m.positions + size_t(m.faces[4 * f]) * 3;
+        const float* p1 = m.positions + size_t(m.faces[4 * f + 1]) * 3;
+        const float* p2 = m.positions + size_t(m.faces[4 * f + 2]) * 3;
+        const double e1[3] = {double(p1[0]) - p0[0], double(p1[1]) - p0[1], double(p1[2]) - p0[2]};
+        const double e2[3] = {double(p2[0]) - p0[0], double(p2[1]) - p0[1], double(p2[2]) - p0[2]};
+        const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        const double a = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz) * uses[mi];
+        const MaterialDev& mt = im.materials[m.faces[4 * f + 3]];
+        area[lobeClass(mt)] += a; total += a;
+      }
+    }
+    double top = 0;
+    for (double a : area) top = std::max(top, a);
+    im.dominantLobeShare = total > 0 ? float(top / total) : 1.0f;
+  }
   return im;
 }
 

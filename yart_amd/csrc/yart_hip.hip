@@ -276,6 +276,7 @@ struct YartScene {
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32;
   DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld;
   DevBuf<uint32_t> infiniteLights, areaLights; DevBuf<float> areaPowerCdf; DevBuf<float> lut;
+  DevBuf<uint8_t> matClass;                // host_scene.hpp::lobeClass per material
   // render scratch (grown on demand, reused across calls)
   DevBuf<uint32_t> pixels; DevBuf<float> L; DevBuf<uint32_t> cursor; DevBuf<unsigned long long> counters;
   DevBuf<uint64_t> spill; DevBuf<float> hdr; DevBuf<uint32_t> probeIn; DevBuf<float> probeOut;
@@ -303,6 +304,11 @@ void uploadScene(YartScene& s) {
   s.texF32.upload(h.texF32); s.lights.upload(h.lights); s.envs.upload(h.envs); s.envData.upload(h.envData); s.envGuide.upload(h.envGuide); s.nodeWorld.upload(h.nodeWorld);
   s.infiniteLights.upload(h.infiniteLights); s.areaLights.upload(h.areaLights);
   s.areaPowerCdf.upload(h.areaPowerCdf); s.lut.upload(h.lut);
+  {
+    std::vector<uint8_t> cls;
+    for (const MaterialDev& m : h.materials) cls.push_back(lobeClass(m));
+    s.matClass.upload(cls);
+  }
   SceneDev d = h.view();       // counts and totals; pointers replaced below
   d.shadeTris = s.shadeTris.p;
   d.bvhNodes = s.bvhNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
@@ -427,6 +433,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const CameraDev cam = makeCamera(camDesc);
   const RenderConst rc = makeRenderConst(p);
   const bool mega = (p.flags & YART_FLAG_MEGAKERNEL) != 0;
+  uint32_t effFlags = p.flags;              // after the per-scene defaults (reported in YartStats::pipeline_flags)
   buildPixelList(s, W, H, p.shard_tile ? p.shard_tile : p.tile_size, p.rank, p.world_size);
   const uint32_t nPix = uint32_t(s.pixelsHost.size());
 
@@ -434,6 +441,9 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   if (startSample == 0) HIP_CHECK(hipMemsetAsync(dOut, 0, size_t(W) * H * 4 * sizeof(float), stream));
   s.cursor.ensure(1); s.counters.ensure(kNumCounters);
   HIP_CHECK(hipMemsetAsync(s.counters.p, 0, kNumCounters * sizeof(unsigned long long), stream));
+#if defined(YART_COUNT_TRAVERSAL)
+  { const unsigned long long zero = 0; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_texTapBytes), &zero, sizeof(zero))); }
+#endif
 
   // lean traversal kernels when the scene allows them (every node transform chain the identity ->
   // identity-only variant); YART_FLAG_GENERAL_TRACE forces the general kernels for everything
@@ -456,7 +466,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);
   const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend<false>), 8);
   const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow<false>), 8);
-  auto kShade = (p.flags & YART_FLAG_SHADE_SORT) ? k_wf_shade<true> : k_wf_shade<false>;
+  auto kShade = (effFlags & YART_FLAG_SHADE_SORT) ? k_wf_shade<true> : k_wf_shade<false>;
   const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(kShade), 8);
   const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(kRetryE), 8);
   const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(kRetryS), 8);
@@ -502,7 +512,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   }
 
   Timer tAll;
-  StageTimer tMega, tExtend, tShade, tConnect, tGmon, tLean;
+  StageTimer tMega, tExtend, tShade, tConnect, tGmon, tLean, tShadeK, tShadowLean;
   uint32_t waves = 0;
   uint64_t renderedSamples = 0;
   HIP_CHECK(hipEventRecord(tAll.a, stream));
@@ -558,6 +568,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         a.qA = s.qA.p; a.qB = s.qB.p; a.qS = s.qS.p; a.qR = s.qR.p; a.counters = s.wfCounters.p;
         a.pixels = s.pixels.p + c0; a.nPaths = n * uint32_t(waveSamples); a.spp = uint32_t(waveSamples);
         a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p; a.stats = s.counters.p; a.spill = s.spill.p;
+        a.matClass = s.matClass.p;
         if (compact) {
           for (int t = 0; t < 2; t++) {
             f4** f = &a.tail[t].ray0;                  // the nine pointers of WfState, in declaration order
@@ -591,14 +602,18 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           HIP_CHECK(hipGetLastError());
           tExtend.end(stream);
           tShade.begin(stream);
+          tShadeK.begin(stream);
           hipLaunchKernelGGL(kShade, dim3(gridShade), dim3(kBlock), 0, stream, a);
           HIP_CHECK(hipGetLastError());
+          tShadeK.end(stream);
           tShade.end(stream);
           tConnect.begin(stream);
           if (general) {
             hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           } else {
+            tShadowLean.begin(stream);
             hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
+            tShadowLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryS, dim3(gridRetryS), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           }
@@ -629,7 +644,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       HIP_CHECK(hipGetLastError());
       tGmon.end(stream);
       HIP_CHECK(hipStreamSynchronize(stream));
-      tMega.resolve(); tExtend.resolve(); tShade.resolve(); tConnect.resolve(); tGmon.resolve(); tLean.resolve();
+      tMega.resolve(); tExtend.resolve(); tShade.resolve(); tConnect.resolve(); tGmon.resolve(); tLean.resolve(); tShadeK.resolve(); tShadowLean.resolve();
     }
     remaining -= waveSamples;
     uint64_t next = (currentWave > 0 || waveSamples > 1) ? std::min<uint64_t>(waveSamples * 2, p.max_wave_samples) : 1;
@@ -653,6 +668,18 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     stats->ms_extend = tExtend.ms; stats->ms_shade = tShade.ms; stats->ms_connect = tConnect.ms; stats->ms_gmon = tGmon.ms;
     stats->ms_extend_lean = tLean.ms; stats->launches_extend_lean = tLean.launches;
     stats->lean_traversals = cnt[5]; stats->lean_box_tests = cnt[6]; stats->lean_tri_tests = cnt[7];
+    stats->ms_shade_kernel = tShadeK.ms; stats->launches_shade_kernel = tShadeK.launches;
+    stats->ms_shadow_lean = tShadowLean.ms; stats->launches_shadow_lean = tShadowLean.launches;
+    stats->shadow_lean_traversals = cnt[24]; stats->shadow_lean_box_tests = cnt[25]; stats->shadow_lean_tri_tests = cnt[26];
+    stats->shade_entries = cnt[28]; stats->retry_extend_traversals = cnt[29]; stats->retry_shadow_traversals = cnt[30];
+    stats->pipeline_flags = effFlags;
+#if defined(YART_COUNT_TRAVERSAL)
+    {
+      unsigned long long tb = 0;
+      HIP_CHECK(hipMemcpyFromSymbol(&tb, HIP_SYMBOL(g_texTapBytes), sizeof(tb)));
+      stats->texture_tap_bytes = tb;
+    }
+#endif
     stats->launches_extend = tExtend.launches; stats->launches_connect = tConnect.launches;
     stats->waves = waves;
     stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();

@@ -54,13 +54,28 @@ def test_two_rank_merge_gloo():
 
 def test_bench_cpu_baseline_leg_runs_on_a_small_case():
     """bench.py's cpu_baseline leg (the compiled reference, or the oracle, timed on the host cores) on a 32x32 case,
-    with the library-only keys the bench carries in its parameter dict."""
+    with the library-only keys the bench carries in its parameter dict: the timing entry, the frame the parity gate
+    compares the GPU render with, and the oracle's test counters in the reference's traversal order."""
     import argparse
+    import numpy as np
     import bench
     from yart_amd import scenes
     scene, p = scenes.cornell(32, 32, 2, 3)
-    cb = bench.cpu_baseline(scene, dict(p, shard_tile=16, estimator=0), argparse.Namespace(cpu_spp=1))
-    if cb is None:
+    res, frame = bench.cpu_baseline(scene, dict(p, shard_tile=16, estimator=0, max_batch_paths=0),
+                                    argparse.Namespace(cpu_spp=1, ref_order_spp=1))
+    if res is None:
         import pytest
         pytest.skip("neither oracle/_ref/yart_ref nor oracle/_build/yart_oracle is built")
+    cb, ref_order = res
     assert cb["unit"] == "Msamples/s" and cb["value"] > 0 and cb["kind"] in ("reference", "port") and cb["cores"] >= 1
+    assert frame.shape == (32, 32, 4) and np.all(frame[..., 3] == 1.0)
+    if ref_order is not None:
+        assert ref_order["traversals"] > ref_order["shadow_traversals"] > 0
+        assert ref_order["box_tests"] > ref_order["shadow_box_tests"] > 0 and ref_order["tri_tests"] > 0
+
+
+def test_bench_kernel_name_parsing():
+    import bench
+    assert bench.kernel_base("void (anonymous namespace)::k_wf_shade<false>((anonymous namespace)::WfArgs)") == "k_wf_shade"
+    assert bench.kernel_base("(anonymous namespace)::k_wf_post((anonymous namespace)::WfArgs)") == "k_wf_post"
+    assert bench.kernel_base("__amd_rocclr_copyBuffer") is None

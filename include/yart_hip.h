@@ -143,8 +143,10 @@ typedef struct YartRenderParams {
 #define YART_FLAG_MEGAKERNEL 1u     /* single-kernel integrator instead of the wavefront pipeline */
 #define YART_FLAG_NO_REFILL 16u     /* one-ray-per-lane lean kernels instead of the ones with in-wave ray
                                        replacement (trace_lean.hpp) */
-#define YART_FLAG_SHADE_SORT 2u     /* bucket each wave's 256 shade-queue entries by material before shading them
-                                       (measured: +5 % shade time on the C3 scene, hence opt-in) */
+#define YART_FLAG_SHADE_SORT 2u     /* bucket each wave's 256 shade-queue entries by lobe class before shading them: the default
+                                       since round 2 (measured: shade stage -8.4 % on the McLaren-class scene, -0.5 % on the
+                                       Sponza-class one; round 1 bucketed by material index and lost 5 % there) */
+#define YART_FLAG_NO_SHADE_SORT 64u /* shade the queue entries in queue order */
 #define YART_FLAG_DIRECT_SAMPLER 8u /* evaluate every ZSobol index digit per draw (no per-render sampler tables) */
 #define YART_FLAG_NO_COMPACTION 32u  /* keep every bounce on the batch-sized path state (no copy of the survivors into a dense one) */
 #define YART_FLAG_GENERAL_TRACE 4u  /* general traversal kernels for every ray instead of lean kernels + retry */

@@ -98,7 +98,7 @@ def test_c5_full_detail_window_of_the_4k_frame(api, tmp_path):
     ref, info = _check(tmp_path, s, p, ORACLE_BIN, shard)
     scene = api.DeviceScene(s, device=0)
     q = dict(p, shard_tile=shard[2])
-    for name in ("wavefront", "wavefront+shade_sort"):
+    for name in ("wavefront", "wavefront+no_shade_sort"):
         img, st = scene.render(q, rank=shard[0], world_size=shard[1], flags=PIPELINE_FLAGS[name])
         assert st["samples"] == info["pixels"] * 512
         same, e = _compare(img, ref, f"mclaren_class 4K x 512 spp, {info['pixels']} pixels / {name}")

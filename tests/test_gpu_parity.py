@@ -33,7 +33,8 @@ def api(built):
 
 
 PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+shade_sort": 2, "wavefront+general_trace": 4,
-                  "wavefront+direct_sampler": 8, "wavefront+no_refill": 16, "wavefront+no_compaction": 32}
+                  "wavefront+direct_sampler": 8, "wavefront+no_refill": 16, "wavefront+no_compaction": 32,
+                  "wavefront+no_shade_sort": 64}
 
 
 @pytest.mark.parametrize("pipeline", list(PIPELINE_FLAGS))
@@ -192,7 +193,7 @@ def test_sponza_class_pipelines_agree(api):
     scene = api.DeviceScene(s, device=0)
     a, st = scene.render(p)
     assert st["rays"] > 0 and np.isfinite(a).all()
-    for name in ("megakernel", "wavefront+shade_sort", "wavefront+general_trace", "wavefront+no_refill", "wavefront"):
+    for name in ("megakernel", "wavefront+no_shade_sort", "wavefront+general_trace", "wavefront+no_refill", "wavefront"):
         b, st2 = scene.render(p, flags=PIPELINE_FLAGS[name])
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
         assert st2["rays"] == st["rays"], name

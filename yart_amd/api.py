@@ -35,6 +35,7 @@ FLAG_GENERAL_TRACE = 4
 FLAG_DIRECT_SAMPLER = 8
 FLAG_NO_REFILL = 16
 FLAG_NO_COMPACTION = 32
+FLAG_NO_SHADE_SORT = 64
 
 
 class YartError(RuntimeError):

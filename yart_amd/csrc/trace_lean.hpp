@@ -34,6 +34,11 @@ constexpr uint32_t kLeanRefill = YART_LEAN_REFILL;      // refill when at least 
 #endif
 constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;   // leave the inner loop when fewer lanes than this still step
 
+// inner loop of part (C): 1 = trace_lean_bvh.inc (round 1), 2 = trace_lean_bvh2.inc (straight-line step, lane state in VGPRs)
+#ifndef YART_LEAN_LOOP
+#define YART_LEAN_LOOP 2
+#endif
+
 struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general variant only (alpha tests)
 
 // Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)
@@ -183,7 +188,11 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
       }
     }
 
+#if YART_LEAN_LOOP == 2
+#include "trace_lean_bvh2.inc"
+#else
 #include "trace_lean_bvh.inc"
+#endif
   }
 #undef LEAN_VISIT
   (void)meshHasAlpha;

@@ -186,7 +186,11 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
     if (__ballot(has && needMask) == 0ull) break;               // a lane moved on to the next node chunk: mask, walk again
     }
 
+#if YART_LEAN_LOOP == 2
+#include "trace_lean_bvh2.inc"
+#else
 #include "trace_lean_bvh.inc"
+#endif
   }
 #undef LEAN_VISIT
   (void)meshHasAlpha;

@@ -433,7 +433,8 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const CameraDev cam = makeCamera(camDesc);
   const RenderConst rc = makeRenderConst(p);
   const bool mega = (p.flags & YART_FLAG_MEGAKERNEL) != 0;
-  uint32_t effFlags = p.flags;              // after the per-scene defaults (reported in YartStats::pipeline_flags)
+  uint32_t effFlags = p.flags;              // after the defaults (reported in YartStats::pipeline_flags)
+  if (!mega && !(effFlags & YART_FLAG_NO_SHADE_SORT)) effFlags |= YART_FLAG_SHADE_SORT;
   buildPixelList(s, W, H, p.shard_tile ? p.shard_tile : p.tile_size, p.rank, p.world_size);
   const uint32_t nPix = uint32_t(s.pixelsHost.size());
 

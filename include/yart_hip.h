@@ -28,6 +28,7 @@ enum {
   YART_E_NO_DEVICE = -2,  /* no usable HIP device */
   YART_E_HIP = -3,        /* a HIP runtime call failed */
   YART_E_IO = -4,         /* scene file could not be read */
+  YART_E_RCCL = -5,       /* an RCCL call of the multi-device merge failed */
   YART_ABORTED = 1        /* yart_hip_render_waves: the wave callback asked to stop (the frame holds the waves done) */
 };
 
@@ -226,11 +227,48 @@ typedef int (*YartWaveCallback)(void* user, const YartStats* wave_stats, uint32_
                                 uint32_t samples_taken, uint32_t total_samples);
 int yart_hip_render_waves(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
                           float* out_rgba, YartStats* stats, YartWaveCallback on_wave, void* user);
+/* Same, with tile granularity (Renderer::onRenderTileComplete, renderer.hpp:40-50, 58; fired by finishTile,
+ * tile-renderer.hpp:243-262 — the frontend uploads each finished tile from it, frontend main.cpp:206). A wave is
+ * rendered batch by batch over this rank's pixel blocks in Morton order (YartRenderParams.max_batch_paths bounds a
+ * batch; blocks are tile_size, or shard_tile, pixels wide); when a batch ends, the blocks it completed are copied into
+ * out_rgba — which then holds, for those pixels, the frame blended up to this wave — and on_tile is called once per
+ * block. A non-zero return stops the render after the current batch (YART_ABORTED; out_rgba then holds whatever had
+ * been blended). The reference's TileData.rays is not reproduced: rays are counted per wave, not per tile (0 here). */
+typedef struct YartTileInfo {
+  uint32_t x, y, width, height;     /* TileData.offset / size */
+  uint32_t index, total;            /* TileData.index (1-based count of finished blocks of this wave) / total */
+  uint32_t wave, wave_samples, samples_taken, total_samples;   /* samples_taken: after this wave */
+  uint64_t rays;                    /* 0 (see above) */
+  double ms;                        /* since the wave started */
+} YartTileInfo;
+typedef int (*YartTileCallback)(void* user, const YartTileInfo* tile);
+int yart_hip_render_tiles(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                          float* out_rgba, YartStats* stats, YartWaveCallback on_wave, YartTileCallback on_tile, void* user);
 /* Same as yart_hip_render, writing a DEVICE buffer (e.g. a torch tensor's data_ptr) on `stream`
  * (hipStream_t, may be NULL); returns after the work has been enqueued and
  * completed on that stream. */
 int yart_hip_render_device(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
                            float* d_out_rgba, void* stream, YartStats* stats);
+
+/* Several GPUs of one node behind one handle — what the reference's worker pool is to CPU threads
+ * (TileRenderer::renderImpl starts threadCount workers that pull tiles, tile-renderer.hpp:150-197; finishTile merges
+ * each finished tile into the one m_hdrBuffer, :225-241). The scene is replicated on every listed device; device i of
+ * N renders the pixel blocks b with b % N == i (blocks of shard_tile / tile_size pixels in Morton order — combined
+ * with params->rank / world_size as device i of N of process rank r of R); one host thread per device drives its
+ * launches; the merge sends each device's OWN pixels (a packed slab, 1/N of the frame) to devices[0] with RCCL
+ * point-to-point calls over xGMI, where they are scattered into the frame, which is then copied to out_rgba.
+ * RCCL failures return YART_E_RCCL. A device listed more than once (rehearsal on a one-GPU box) is served by a
+ * device-to-device copy instead of RCCL, everything else being the same; bound max_batch_paths then, the replicas
+ * share that device's memory. Blocking; the frame equals the single-device render bit for bit. */
+typedef struct YartMulti YartMulti;
+int yart_hip_multi_create(const YartSceneDesc* desc, const int* devices, uint32_t n_devices, YartMulti** out);
+/* from a .yscn container or a .glb / .gltf asset (opts as for yart_hip_scene_load_gltf; ignored for .yscn) */
+int yart_hip_multi_load(const char* path, const YartImportOptions* opts, const int* devices, uint32_t n_devices, YartMulti** out);
+void yart_hip_multi_destroy(YartMulti* multi);
+int yart_hip_multi_device_count(const YartMulti* multi);
+/* stats: samples / rays / test counters summed over the devices, ms_* the slowest device's, ms_total the call's wall time */
+int yart_hip_multi_render(YartMulti* multi, const YartCameraDesc* cam, const YartRenderParams* params, float* out_rgba,
+                          YartStats* stats);
 
 /* Diagnostics (device code paths, used by the parity tests):
  * per-sample radiance (before exposure) of n (x, y, sample) triples -> 3 floats each */

@@ -70,3 +70,27 @@ def test_adapter_waves_follow_the_reference_schedule(tmp_path):
     want, _ = scene.render(p)
     scene.close()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@needs_exe
+@pytest.mark.gpu
+def test_adapter_tile_callbacks_and_multi_device(tmp_path):
+    """HipRenderer with onRenderTileComplete set (yart_hip_render_tiles: Renderer::TileData per finished tile, the
+    renderer's buffer holding the tonemapped tile) and with a MultiDeviceScene (yart_hip_multi_render; GPU 0 named
+    twice on a one-GPU box): both give the frame of the plain adapter render."""
+    p = load_params(os.path.join(G, "gallery.txt"))
+    w, h = p["size"]
+    ref = np.fromfile(os.path.join(G, "gallery.f32"), np.float32).reshape(h, w, 4)
+    out = os.path.join(tmp_path, "t.f32")
+    base = [EXE, os.path.join(G, "gallery.glb"), os.path.join(G, "env_rle.hdr"), os.path.join(G, "gallery.txt"), out, "-"]
+    r = subprocess.run(base + ["tiles=20000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    tiles = [l for l in r.stdout.splitlines() if l.startswith("tile")]
+    n_tiles = ((w + 63) // 64) * ((h + 63) // 64)
+    assert len(tiles) == n_tiles and tiles[-1].startswith(f"tile {n_tiles}/{n_tiles}")
+    got = np.fromfile(out, np.float32).reshape(h, w, 4)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    r = subprocess.run(base + ["tiles=262144", "devices=0,0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(out, np.float32).reshape(h, w, 4)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

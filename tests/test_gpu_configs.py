@@ -150,3 +150,75 @@ def test_hit_records_vs_reference_kat(api, case):
     want = np.ascontiguousarray(np.concatenate([hf[hit, 0:1], hf[hit, 3:12]], axis=1))
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
     scene.close()
+
+
+def test_tile_callback_reports_every_block_once_per_wave(api):
+    """yart_hip_render_tiles (Renderer::onRenderTileComplete, renderer.hpp:40-50, tile-renderer.hpp:243-262): with
+    batches of at most ~two tiles, every tile of every wave is reported exactly once, in Morton order, with the
+    frame holding that tile's blended pixels at the time of the call; the final frame is the plain render; stopping
+    from a tile callback returns the frame with exactly the tiles reported so far blended."""
+    from yart_amd import dist as yd
+    base = os.path.join(GOLDEN, "cornell")           # 128 x 128: four 64-pixel tiles, 16 spp
+    p = dict(load_params(base + ".txt"), first_wave=4, max_wave=12, max_batch_paths=2 * 64 * 64 * 4 + 7)
+    scene = api.DeviceScene(base + ".yscn", device=0)
+    plain, _ = scene.render(p)
+    first_wave, _ = scene.render(dict(p, stop_sample=4))
+    seen, frames = [], []
+
+    def on_tile(frame, t):
+        seen.append((t["wave"], t["x"], t["y"], t["width"], t["height"], t["index"], t["total"], t["samples_taken"]))
+        frames.append(frame[t["y"]:t["y"] + t["height"], t["x"]:t["x"] + t["width"]].copy())
+    waves = []
+    img, st, aborted = scene.render_tiles(p, on_tile, lambda f, info: waves.append(info["wave"]) and None)
+    assert not aborted and np.array_equal(img.view(np.uint32), plain.view(np.uint32))
+    assert waves == [0, 1] and len(seen) == 8
+    order = [(0, 0), (64, 0), (0, 64), (64, 64)]     # Morton order of the tile coordinates
+    for w in range(2):
+        got = seen[4 * w:4 * w + 4]
+        assert [(g[1], g[2]) for g in got] == order
+        assert [g[5] for g in got] == [1, 2, 3, 4] and all(g[0] == w and g[6] == 4 and g[3] == g[4] == 64 for g in got)
+        assert all(g[7] == (4, 16)[w] for g in got)
+    for k, (x, y) in enumerate(order):               # wave 0's tiles hold the first wave's pixels, wave 1's the final ones
+        assert np.array_equal(frames[k].view(np.uint32), first_wave[y:y + 64, x:x + 64].view(np.uint32))
+        assert np.array_equal(frames[4 + k].view(np.uint32), plain[y:y + 64, x:x + 64].view(np.uint32))
+    # stop at the third tile of the first wave: batches hold two tiles, so the second batch has finished -> 4 tiles in
+    count = []
+    img2, st2, aborted2 = scene.render_tiles(p, lambda f, t: count.append(1) or len(count) >= 3)
+    assert aborted2 and np.array_equal(img2.view(np.uint32), first_wave.view(np.uint32))
+    # sharded: a rank reports only its own blocks (16-pixel blocks, rank 1 of 3)
+    mine = []
+    q = dict(p, shard_tile=16, first_wave=16, max_wave=16)
+    part, _, _ = scene.render_tiles(q, lambda f, t: mine.append((t["x"], t["y"])) and None, rank=1, world_size=3)
+    mask = yd.pixel_mask(128, 128, 16, 1, 3)
+    assert len(mine) == mask.sum() // 256 and all(mask[y, x] for x, y in mine)
+    assert np.array_equal(part[..., 3] == 1.0, mask)
+    scene.close()
+
+
+def test_multi_device_entry_equals_single_device(api):
+    """yart_hip_multi_*: replicas + one host thread each + slab merge. On a one-GPU box the device list names GPU 0
+    several times (the transport is then a device-to-device copy, everything else — dealing of the blocks, threads,
+    pack / scatter — is what an 8-GPU node runs, where ncclSend / ncclRecv carry the slabs): the merged frame is the
+    single-device frame bit for bit, with whole tiles and with 16-pixel blocks, one wave and several, and when the call
+    is itself one rank of two processes."""
+    from yart_amd import scenes
+    s, p = scenes.sponza_class(240, 136, 8, 6, tex=128, sky=128)
+    p = dict(p, max_batch_paths=1 << 18)             # the replicas of the rehearsal share one GPU's memory
+    single = api.DeviceScene(s, device=0)
+    want, st1 = single.render(p)
+    multi = api.MultiDeviceScene(s, [0, 0, 0])
+    assert multi.n_devices == 3
+    got, st = multi.render(p)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert st["samples"] == st1["samples"] and st["rays"] == st1["rays"]
+    q = dict(p, shard_tile=16, first_wave=2, max_wave=4)
+    want2, _ = single.render(q)
+    got2, _ = multi.render(q)
+    assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+    halves = [multi.render(q, rank=r, world_size=2)[0] for r in range(2)]
+    assert np.array_equal((halves[0] + halves[1]).view(np.uint32), want2.view(np.uint32))
+    multi.close()
+    one = api.MultiDeviceScene(s, [0])               # a single device: no merge at all
+    got1, _ = one.render(p)
+    assert np.array_equal(got1.view(np.uint32), want.view(np.uint32))
+    one.close(); single.close()

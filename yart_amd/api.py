@@ -27,8 +27,10 @@ from . import yscn
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyart_hip.so")
+if os.environ.get("YART_LIB_VARIANT"):      # experiment builds of tools/build_variant.sh (yart_amd/_variants/NAME.so)
+    LIB_PATH = os.path.join(_HERE, "_variants", os.environ["YART_LIB_VARIANT"] + ".so")
 
-YART_OK, YART_E_INVALID, YART_E_NO_DEVICE, YART_E_HIP, YART_E_IO = 0, -1, -2, -3, -4
+YART_OK, YART_E_INVALID, YART_E_NO_DEVICE, YART_E_HIP, YART_E_IO, YART_E_RCCL = 0, -1, -2, -3, -4, -5
 FLAG_MEGAKERNEL = 1
 FLAG_SHADE_SORT = 2
 FLAG_GENERAL_TRACE = 4
@@ -131,6 +133,20 @@ YART_ABORTED = 1
 WAVE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 
 
+class TileInfo(C.Structure):
+    """YartTileInfo (include/yart_hip.h): Renderer::TileData of a finished pixel block (renderer.hpp:40-50)."""
+    _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("index", C.c_uint32), ("total", C.c_uint32), ("wave", C.c_uint32), ("wave_samples", C.c_uint32),
+                ("samples_taken", C.c_uint32), ("total_samples", C.c_uint32), ("rays", C.c_uint64), ("ms", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# int on_tile(void* user, const YartTileInfo* tile)
+TILE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TileInfo))
+
+
 class ImportOptions(C.Structure):
     """YartImportOptions (include/yart_hip.h): the environment the frontend adds after gltf::load."""
     _fields_ = [("env_hdr_path", C.c_char_p), ("env_radius", C.c_float), ("uniform_env", C.c_uint32),
@@ -162,9 +178,11 @@ def gltf_to_yscn(gltf_path, yscn_path, env_hdr=None, env_radius=100.0, uniform_e
 EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error",
            "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
            "yart_hip_scene_load_gltf", "yart_hip_gltf_to_yscn",
-           "yart_hip_render", "yart_hip_render_waves", "yart_hip_render_device", "yart_hip_probe_samples",
+           "yart_hip_render", "yart_hip_render_waves", "yart_hip_render_tiles", "yart_hip_render_device", "yart_hip_probe_samples",
            "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_debug_counters",
-           "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host"]
+           "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host",
+           "yart_hip_multi_create", "yart_hip_multi_load", "yart_hip_multi_destroy", "yart_hip_multi_device_count",
+           "yart_hip_multi_render"]
 
 LIB_COUNT_PATH = os.path.join(_HERE, "libyart_hip_count.so")   # instrumented twin (exact test counters)
 _libs = {}
@@ -191,6 +209,8 @@ def lib(instrumented: bool = False):
                                       C.c_void_p, C.POINTER(Stats)]
         L.yart_hip_render_waves.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p,
                                             C.POINTER(Stats), WAVE_CALLBACK, C.c_void_p]
+        L.yart_hip_render_tiles.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p,
+                                            C.POINTER(Stats), WAVE_CALLBACK, TILE_CALLBACK, C.c_void_p]
         L.yart_hip_render_device.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
                                              C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.yart_hip_probe_samples.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
@@ -199,6 +219,12 @@ def lib(instrumented: bool = False):
         L.yart_hip_tonemap_agx.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.yart_hip_encode_rgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.yart_hip_tonemap_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.yart_hip_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]
+        L.yart_hip_multi_load.argtypes = [C.c_char_p, C.POINTER(ImportOptions), C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]
+        L.yart_hip_multi_destroy.argtypes = [C.c_void_p]
+        L.yart_hip_multi_destroy.restype = None
+        L.yart_hip_multi_device_count.argtypes = [C.c_void_p]
+        L.yart_hip_multi_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
         L.yart_hip_bvh_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.yart_hip_bvh_copy.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _libs[path] = L
@@ -344,6 +370,40 @@ class DeviceScene:
             _check(rc, self._L)
         return out, st.asdict(), rc == YART_ABORTED
 
+    def render_tiles(self, p: dict, on_tile=None, on_wave=None, rank=0, world_size=1, flags=0, accumulated=None):
+        """Like :meth:`render_waves`, with tile granularity (Renderer::onRenderTileComplete): ``on_tile(frame, tile)``
+        is called for every pixel block a batch of a wave has finished, ``frame`` being the output array (holding the
+        blended values of that block) and ``tile`` a dict of YartTileInfo; a true return stops the render.
+        ``p["max_batch_paths"]`` bounds a batch, i.e. how many blocks arrive together. Returns (frame, stats, aborted)."""
+        cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
+        out = np.empty((cam.height, cam.width, 4), np.float32)
+        if accumulated is not None:
+            out[...] = accumulated
+        errors = []
+
+        def wave_tr(_user, _stats, wave, wave_samples, taken, total):
+            try:
+                return 1 if on_wave(out, dict(wave=wave, wave_samples=wave_samples, samples_taken=taken, total_samples=total)) else 0
+            except BaseException as e:
+                errors.append(e)
+                return 1
+
+        def tile_tr(_user, tile):
+            try:
+                return 1 if on_tile(out, tile.contents.asdict()) else 0
+            except BaseException as e:
+                errors.append(e)
+                return 1
+        wcb = WAVE_CALLBACK(wave_tr) if on_wave else WAVE_CALLBACK()
+        tcb = TILE_CALLBACK(tile_tr) if on_tile else TILE_CALLBACK()
+        rc = self._L.yart_hip_render_tiles(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p),
+                                           C.byref(st), wcb, tcb, None)
+        if errors:
+            raise errors[0]
+        if rc != YART_ABORTED:
+            _check(rc, self._L)
+        return out, st.asdict(), rc == YART_ABORTED
+
     def render_into(self, tensor, p: dict, rank=0, world_size=1, flags=0, stream=None):
         """Render into a CUDA/HIP torch tensor of shape (H, W, 4) float32 (device memory)."""
         cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
@@ -386,6 +446,48 @@ class DeviceScene:
         return nodes, idx
 
 
+class MultiDeviceScene:
+    """Owns a ``YartMulti*``: the scene replicated on several GPUs of this node, one host thread per device, pixel
+    blocks dealt round-robin, the devices' own pixels merged on ``devices[0]`` with RCCL send / recv (include/yart_hip.h;
+    stands where TileRenderer's worker pool and finishTile's merge stand, tile-renderer.hpp:150-197, 225-241)."""
+
+    def __init__(self, scene, devices: Sequence[int], env_hdr=None, env_radius=100.0, uniform_env=None):
+        self._h = C.c_void_p()
+        self._L = lib()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        if isinstance(scene, (str, os.PathLike)):
+            o = import_options(env_hdr, env_radius, uniform_env)
+            _check(self._L.yart_hip_multi_load(os.fspath(scene).encode(), C.byref(o), devs, len(devices), C.byref(self._h)), self._L)
+        else:
+            helper = DeviceScene.__new__(DeviceScene)
+            helper._keep = []
+            desc = DeviceScene._describe(helper, scene)
+            _check(self._L.yart_hip_multi_create(C.byref(desc), devs, len(devices), C.byref(self._h)), self._L)
+
+    @property
+    def n_devices(self):
+        return int(self._L.yart_hip_multi_device_count(self._h))
+
+    def render(self, p: dict, rank=0, world_size=1, flags=0, accumulated=None):
+        cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
+        out = np.empty((cam.height, cam.width, 4), np.float32)
+        if accumulated is not None:
+            out[...] = accumulated
+        _check(self._L.yart_hip_multi_render(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p), C.byref(st)), self._L)
+        return out, st.asdict()
+
+    def close(self):
+        if self._h:
+            self._L.yart_hip_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 @dataclass
 class RenderData:
     """Mirror of ``yart::Renderer::RenderData`` (reference src/core/renderer.hpp:22-28)."""
@@ -414,9 +516,11 @@ class HipTileRenderer:
         self.scene: Optional[DeviceScene] = None
         self.tonemapper = None            # AgX look name ("none" / "golden" / "punchy") or None: linear HDR buffer
         self.estimator = ESTIMATOR_GMON   # integrator.cpp:17-18 fixes it at compile time
-        self.on_render_complete = None    # callbacks of renderer.hpp:55-58; the tile callback has no counterpart
-        self.on_render_aborted = None     # (a wave is a handful of launches over all tiles)
+        self.on_render_complete = None    # callbacks of renderer.hpp:55-58
+        self.on_render_aborted = None
         self.on_render_wave_complete = None   # f(RenderData, dict(wave, wave_samples, samples_taken, total_samples))
+        self.on_render_tile_complete = None   # f(RenderData, dict of YartTileInfo): per finished pixel block of a batch
+        self.max_batch_paths = 0              # YartRenderParams.max_batch_paths: how many blocks finish together (0: all)
         self._camera = dict(camera, size=(width, height))
         self._device = device
         self._thread: Optional[threading.Thread] = None
@@ -426,7 +530,7 @@ class HipTileRenderer:
     def _params(self):
         return dict(self._camera, spp=self.samples, first_wave=min(self.first_wave_samples, self.samples),
                     max_wave=self.max_wave_samples, tile=self.tile_size, depth=self.max_depth,
-                    background=self.background_color, estimator=self.estimator)
+                    background=self.background_color, estimator=self.estimator, max_batch_paths=self.max_batch_paths)
 
     def render_sync(self) -> RenderData:
         if self.scene is None:           # Integrator::render: "if (!scene) return" (integrator.cpp:6)
@@ -445,7 +549,19 @@ class HipTileRenderer:
                 self.on_render_wave_complete(RenderData(shown(frame), info["samples_taken"], self.samples, 0,
                                                         (time.perf_counter() - t0) * 1e3, {}), info)
             return self._abort
-        buf, st, _ = self.scene.render_waves(self._params(), on_wave)
+        if self.on_render_tile_complete:
+            def on_tile(frame, tile):
+                x, y, w, h = tile["x"], tile["y"], tile["width"], tile["height"]
+                view = frame
+                if self.tonemapper:        # tile-renderer.hpp:234-239 maps the finished tile only
+                    view = frame.copy()
+                    view[y:y + h, x:x + w] = tonemap(np.ascontiguousarray(frame[y:y + h, x:x + w]), self.tonemapper)[0]
+                self.on_render_tile_complete(RenderData(view, tile["samples_taken"] - tile["wave_samples"], self.samples, 0,
+                                                        (time.perf_counter() - t0) * 1e3, {}), tile)
+                return self._abort
+            buf, st, _ = self.scene.render_tiles(self._params(), on_tile, on_wave)
+        else:
+            buf, st, _ = self.scene.render_waves(self._params(), on_wave)
         ms = (time.perf_counter() - t0) * 1e3
         self._result = RenderData(shown(buf), taken[0], self.samples, st["rays"], ms, st)
         return self._result

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -287,6 +288,8 @@ struct YartScene {
   DevBuf<uint32_t> qA, qB, qS, qR, wfCounters; // wavefront queues
   DevBuf<uint64_t> smpEntries, smpHash; DevBuf<uint32_t> smpSobol1;   // SamplerTables of the current render
   std::vector<uint32_t> pixelsHost;
+  struct TileRec { uint32_t x, y, w, h, start, count; };     // a pixel block of this rank: its rectangle and its range of pixelsHost
+  std::vector<TileRec> tiles;
   unsigned long long lastCounters[32] = {0};
   uint32_t pixW = 0, pixH = 0, pixTile = 0, pixRank = 0, pixWorld = 0;
   std::mutex mu;
@@ -351,21 +354,28 @@ uint32_t morton2(uint32_t x, uint32_t y) { return uint32_t(encodeMorton2(x, y));
 // Pixels of the tiles this rank owns, tile-major (row-major inside a tile). Tiles are
 // the reference's unit of parallel work (tile-renderer.hpp:126-144); across ranks they
 // are dealt round-robin in Morton order.
-void buildPixelList(YartScene& s, uint32_t W, uint32_t H, uint32_t tile, uint32_t rank, uint32_t world) {
-  if (s.pixW == W && s.pixH == H && s.pixTile == tile && s.pixRank == rank && s.pixWorld == world) return;
+std::vector<uint32_t> makePixelList(uint32_t W, uint32_t H, uint32_t tile, uint32_t rank, uint32_t world,
+                                    std::vector<YartScene::TileRec>* tilesOut) {
   const uint32_t tx = (W + tile - 1) / tile, ty = (H + tile - 1) / tile;
   std::vector<std::pair<uint32_t, uint32_t>> order;   // (morton, linear tile)
   for (uint32_t y = 0; y < ty; y++)
     for (uint32_t x = 0; x < tx; x++) order.push_back({morton2(x, y), y * tx + x});
   std::sort(order.begin(), order.end());
-  s.pixelsHost.clear();
+  std::vector<uint32_t> pixels;
+  if (tilesOut) tilesOut->clear();
   for (size_t k = 0; k < order.size(); k++) {
     if (k % world != rank) continue;
     const uint32_t x0 = (order[k].second % tx) * tile, y0 = (order[k].second / tx) * tile;
     const uint32_t x1 = std::min(W, x0 + tile), y1 = std::min(H, y0 + tile);
+    if (tilesOut) tilesOut->push_back({x0, y0, x1 - x0, y1 - y0, uint32_t(pixels.size()), (x1 - x0) * (y1 - y0)});
     for (uint32_t y = y0; y < y1; y++)
-      for (uint32_t x = x0; x < x1; x++) s.pixelsHost.push_back(x | (y << 16));
+      for (uint32_t x = x0; x < x1; x++) pixels.push_back(x | (y << 16));
   }
+  return pixels;
+}
+void buildPixelList(YartScene& s, uint32_t W, uint32_t H, uint32_t tile, uint32_t rank, uint32_t world) {
+  if (s.pixW == W && s.pixH == H && s.pixTile == tile && s.pixRank == rank && s.pixWorld == world) return;
+  s.pixelsHost = makePixelList(W, H, tile, rank, world, &s.tiles);
   s.pixels.upload(s.pixelsHost);
   s.pixW = W; s.pixH = H; s.pixTile = tile; s.pixRank = rank; s.pixWorld = world;
 }
@@ -425,8 +435,14 @@ struct StageTimer {
   }
 };
 
-void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRenderParams& p, float* dOut,
-                    hipStream_t stream, YartStats* stats) {
+// Called after every batch of a wave, once its pixels are final for that wave in the output frame (the stream has been
+// synchronised): the range [c0, c0 + n) of this rank's pixel list. Returning true stops the render after this batch.
+struct BatchInfo { uint32_t c0, n, wave, waveSamples, samplesTaken, totalSamples; };
+typedef std::function<bool(const BatchInfo&)> BatchHook;
+
+bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRenderParams& p, float* dOut,
+                    hipStream_t stream, YartStats* stats, const BatchHook* hook = nullptr) {
+  bool aborted = false;
   auto wall0 = std::chrono::high_resolution_clock::now();
   HIP_CHECK(hipSetDevice(s.device));
   const uint32_t W = camDesc.width, H = camDesc.height;
@@ -549,7 +565,7 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     if (!inRange && takenBefore < startSample && takenAfter > startSample) throw std::invalid_argument("start_sample is not a wave boundary");
     if (inRange && takenAfter > stopSample) throw std::invalid_argument("stop_sample is not a wave boundary");
     if (inRange) { waves++; renderedSamples += waveSamples; }
-    for (uint32_t c0 = 0; inRange && c0 < nPix; c0 += chunk) {
+    for (uint32_t c0 = 0; inRange && !aborted && c0 < nPix; c0 += chunk) {
       const uint32_t n = std::min(chunk, nPix - c0);
       if (mega) {
         HIP_CHECK(hipMemsetAsync(s.cursor.p, 0, sizeof(uint32_t), stream));
@@ -646,7 +662,12 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       tGmon.end(stream);
       HIP_CHECK(hipStreamSynchronize(stream));
       tMega.resolve(); tExtend.resolve(); tShade.resolve(); tConnect.resolve(); tGmon.resolve(); tLean.resolve(); tShadeK.resolve(); tShadowLean.resolve();
+      if (hook && *hook) {
+        const BatchInfo bi{c0, n, uint32_t(currentWave), uint32_t(waveSamples), uint32_t(takenAfter), p.samples};
+        if ((*hook)(bi)) aborted = true;
+      }
     }
+    if (aborted) break;
     remaining -= waveSamples;
     uint64_t next = (currentWave > 0 || waveSamples > 1) ? std::min<uint64_t>(waveSamples * 2, p.max_wave_samples) : 1;
     waveSamples = std::min(next, remaining);
@@ -685,13 +706,18 @@ void renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     stats->waves = waves;
     stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - wall0).count();
   }
+  return aborted;
 }
+
+struct RcclFailure : std::runtime_error { using std::runtime_error::runtime_error; };
 
 template <class F>
 int guarded(F&& f) {
   try {
     f();
     return YART_OK;
+  } catch (const RcclFailure& e) {
+    g_lastError = e.what(); return YART_E_RCCL;
   } catch (const std::invalid_argument& e) {
     g_lastError = e.what(); return YART_E_INVALID;
   } catch (const HipError& e) {
@@ -717,6 +743,8 @@ std::unique_ptr<LoadedScene> importGltf(const char* path, const YartImportOption
   return loaded;
 }
 }  // namespace
+
+#include "multi_device.inc"
 
 extern "C" {
 
@@ -795,8 +823,10 @@ int yart_hip_render(YartScene* scene, const YartCameraDesc* cam, const YartRende
   });
 }
 
-int yart_hip_render_waves(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
-                          float* out_rgba, YartStats* stats, YartWaveCallback on_wave, void* user) {
+// One wave of the schedule at a time, and inside a wave one batch at a time (tile-renderer.hpp:200-309: finishTile
+// fires onRenderTileComplete per tile and onRenderWaveComplete after a wave's last tile).
+static int renderProgressive(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params, float* out_rgba,
+                             YartStats* stats, YartWaveCallback on_wave, YartTileCallback on_tile, void* user) {
   bool aborted = false;
   const int rc = guarded([&] {
     require(scene && out_rgba, "scene / output pointer is null");
@@ -804,10 +834,12 @@ int yart_hip_render_waves(YartScene* scene, const YartCameraDesc* cam, const Yar
     std::lock_guard<std::mutex> lock(scene->mu);
     auto t0 = std::chrono::high_resolution_clock::now();
     HIP_CHECK(hipSetDevice(scene->device));
-    const size_t n = size_t(cam->width) * cam->height * 4;
+    const uint32_t W = cam->width, H = cam->height;
+    const size_t n = size_t(W) * H * 4;
     scene->hdr.ensure(n);
     const uint32_t stop = params->stop_sample ? params->stop_sample : params->samples;
     if (params->start_sample > 0) HIP_CHECK(hipMemcpy(scene->hdr.p, out_rgba, n * sizeof(float), hipMemcpyHostToDevice));
+    else if (on_tile) std::memset(out_rgba, 0, n * sizeof(float));       // tiles arrive one by one: the rest of the frame is defined
     YartStats total{};
     // the wave schedule of tile-renderer.hpp:264-289 (renderToDevice walks the same one): w0 = min(first, samples),
     // then min(2 w, max) — a first wave of one sample is followed by another single one
@@ -819,13 +851,36 @@ int yart_hip_render_waves(YartScene* scene, const YartCameraDesc* cam, const Yar
         YartRenderParams q = *params;
         q.start_sample = taken; q.stop_sample = uint32_t(taken + waveSamples);
         YartStats st{};
-        renderToDevice(*scene, *cam, q, scene->hdr.p, nullptr, &st);
-        HIP_CHECK(hipMemcpy(out_rgba, scene->hdr.p, n * sizeof(float), hipMemcpyDeviceToHost));
-        total.rays += st.rays; total.waves += st.waves; total.ms_device += st.ms_device;
+        auto tw = std::chrono::high_resolution_clock::now();
+        size_t nextTile = 0;                 // tiles are in pixel-list order: everything before nextTile has been reported
+        BatchHook hook = [&](const BatchInfo& b) {
+          // the tiles whose last pixel lies in this batch are final for this wave: copy them out and report them
+          const auto& tiles = scene->tiles;
+          bool stopNow = false;
+          while (nextTile < tiles.size() && tiles[nextTile].start + tiles[nextTile].count <= b.c0 + b.n) {
+            const YartScene::TileRec& t = tiles[nextTile++];
+            const size_t off = (size_t(t.y) * W + t.x) * 4;
+            HIP_CHECK(hipMemcpy2D(out_rgba + off, size_t(W) * 16, scene->hdr.p + off, size_t(W) * 16, size_t(t.w) * 16, t.h,
+                                  hipMemcpyDeviceToHost));
+            YartTileInfo ti{};
+            ti.x = t.x; ti.y = t.y; ti.width = t.w; ti.height = t.h;
+            ti.index = uint32_t(nextTile); ti.total = uint32_t(tiles.size());
+            ti.wave = b.wave; ti.wave_samples = b.waveSamples; ti.samples_taken = b.samplesTaken; ti.total_samples = b.totalSamples;
+            ti.ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - tw).count();
+            if (on_tile(user, &ti) != 0) stopNow = true;
+          }
+          return stopNow;
+        };
+        const bool stopped = renderToDevice(*scene, *cam, q, scene->hdr.p, nullptr, &st, on_tile ? &hook : nullptr);
+        // after a wave the whole frame (with a tile callback: every tile has been copied already unless the render stopped)
+        if (!on_tile || stopped) HIP_CHECK(hipMemcpy(out_rgba, scene->hdr.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        total.rays += st.rays; total.waves += st.waves; total.ms_device += st.ms_device; total.samples += st.samples;
         total.ms_extend += st.ms_extend; total.ms_shade += st.ms_shade; total.ms_connect += st.ms_connect; total.ms_gmon += st.ms_gmon;
         total.ms_traverse += st.ms_traverse; total.launches_traverse += st.launches_traverse;
+        total.pipeline_flags = st.pipeline_flags;
         st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
-        if (on_wave && on_wave(user, &st, uint32_t(wave), uint32_t(waveSamples), uint32_t(taken + waveSamples), params->samples) != 0)
+        if (stopped) aborted = true;
+        else if (on_wave && on_wave(user, &st, uint32_t(wave), uint32_t(waveSamples), uint32_t(taken + waveSamples), params->samples) != 0)
           aborted = true;
       }
       remaining -= waveSamples;
@@ -837,6 +892,46 @@ int yart_hip_render_waves(YartScene* scene, const YartCameraDesc* cam, const Yar
     if (stats) *stats = total;
   });
   return rc == YART_OK && aborted ? YART_ABORTED : rc;
+}
+
+int yart_hip_render_waves(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                          float* out_rgba, YartStats* stats, YartWaveCallback on_wave, void* user) {
+  return renderProgressive(scene, cam, params, out_rgba, stats, on_wave, nullptr, user);
+}
+
+int yart_hip_render_tiles(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
+                          float* out_rgba, YartStats* stats, YartWaveCallback on_wave, YartTileCallback on_tile, void* user) {
+  return renderProgressive(scene, cam, params, out_rgba, stats, on_wave, on_tile, user);
+}
+
+int yart_hip_multi_create(const YartSceneDesc* desc, const int* devices, uint32_t n_devices, YartMulti** out) {
+  return guarded([&] {
+    require(desc && out, "desc / out pointer is null");
+    *out = createMulti(*desc, devices, n_devices);
+  });
+}
+
+int yart_hip_multi_load(const char* path, const YartImportOptions* opts, const int* devices, uint32_t n_devices, YartMulti** out) {
+  return guarded([&] {
+    require(path && out, "path / out pointer is null");
+    const std::string p(path);
+    const bool gltf = p.size() > 4 && (p.rfind(".glb") == p.size() - 4 || p.rfind(".gltf") == p.size() - 5);
+    auto loaded = gltf ? importGltf(path, opts) : loadSceneFile(path);
+    *out = createMulti(loaded->desc, devices, n_devices);
+  });
+}
+
+void yart_hip_multi_destroy(YartMulti* multi) { delete multi; }
+
+int yart_hip_multi_device_count(const YartMulti* multi) { return multi ? int(multi->scenes.size()) : 0; }
+
+int yart_hip_multi_render(YartMulti* multi, const YartCameraDesc* cam, const YartRenderParams* params, float* out_rgba,
+                          YartStats* stats) {
+  return guarded([&] {
+    require(multi && out_rgba, "multi / output pointer is null");
+    validate(cam, params);
+    renderMulti(*multi, *cam, *params, out_rgba, stats);
+  });
 }
 
 int yart_hip_probe_samples(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,

@@ -159,10 +159,10 @@ def test_tile_callback_reports_every_block_once_per_wave(api):
     from a tile callback returns the frame with exactly the tiles reported so far blended."""
     from yart_amd import dist as yd
     base = os.path.join(GOLDEN, "cornell")           # 128 x 128: four 64-pixel tiles, 16 spp
-    p = dict(load_params(base + ".txt"), first_wave=4, max_wave=12, max_batch_paths=2 * 64 * 64 * 4 + 7)
+    p = dict(load_params(base + ".txt"), first_wave=8, max_wave=8, max_batch_paths=2 * 64 * 64 * 8 + 7)   # waves of 8 + 8 spp
     scene = api.DeviceScene(base + ".yscn", device=0)
     plain, _ = scene.render(p)
-    first_wave, _ = scene.render(dict(p, stop_sample=4))
+    first_wave, _ = scene.render(dict(p, stop_sample=8))
     seen, frames = [], []
 
     def on_tile(frame, t):
@@ -177,7 +177,7 @@ def test_tile_callback_reports_every_block_once_per_wave(api):
         got = seen[4 * w:4 * w + 4]
         assert [(g[1], g[2]) for g in got] == order
         assert [g[5] for g in got] == [1, 2, 3, 4] and all(g[0] == w and g[6] == 4 and g[3] == g[4] == 64 for g in got)
-        assert all(g[7] == (4, 16)[w] for g in got)
+        assert all(g[7] == (8, 16)[w] for g in got)
     for k, (x, y) in enumerate(order):               # wave 0's tiles hold the first wave's pixels, wave 1's the final ones
         assert np.array_equal(frames[k].view(np.uint32), first_wave[y:y + 64, x:x + 64].view(np.uint32))
         assert np.array_equal(frames[4 + k].view(np.uint32), plain[y:y + 64, x:x + 64].view(np.uint32))

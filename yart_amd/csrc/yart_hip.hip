@@ -272,7 +272,7 @@ struct YartScene {
   SceneDev dev{};
   int numCUs = 256;
   // device copies of the scene image
-  DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
+  DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<Wide4> wideNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32;
   DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld;
@@ -300,7 +300,7 @@ namespace {
 void uploadScene(YartScene& s) {
   const HostImage& h = s.host;
   s.shadeTris.upload(h.shadeTris);
-  s.bvhNodes.upload(h.bvhNodes); s.leafTris.upload(h.leafTris); s.triVerts.upload(h.triVerts);
+  s.bvhNodes.upload(h.bvhNodes); s.wideNodes.upload(h.wideNodes); s.leafTris.upload(h.leafTris); s.triVerts.upload(h.triVerts);
   s.triLight.upload(h.triLight); s.vPos.upload(h.vPos); s.vNormal.upload(h.vNormal);
   s.vTangent.upload(h.vTangent); s.vUV.upload(h.vUV); s.meshes.upload(h.meshes); s.nodes.upload(h.nodes);
   s.materials.upload(h.materials); s.textures.upload(h.textures); s.texU8.upload(h.texU8);
@@ -314,7 +314,7 @@ void uploadScene(YartScene& s) {
   }
   SceneDev d = h.view();       // counts and totals; pointers replaced below
   d.shadeTris = s.shadeTris.p;
-  d.bvhNodes = s.bvhNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
+  d.bvhNodes = s.bvhNodes.p; d.wideNodes = s.wideNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
   d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.lights = s.lights.p; d.envs = s.envs.p;
@@ -470,12 +470,24 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // trace_lean.hpp keeps one 64-bit node candidate mask per ray and uses the all-ones mask as its "new ray"
   // marker, which a ray that can reach all of exactly 64 nodes would keep: 64 nodes and more go to the chunked form
   const bool chunked = s.host.nodes.size() >= 64;
-  auto kExtendFast = !refill ? (ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>)
-                   : chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_extend_lean<TRAV_FAST, true>)
-                             : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_extend_lean<TRAV_FAST, false>);
-  auto kShadowFast = !refill ? (ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>)
-                   : chunked ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_shadow_lean<TRAV_FAST, true>)
-                             : (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_shadow_lean<TRAV_FAST, false>);
+  // TRAV_WIDE: the lean kernels walk the 4-wide records (wide_bvh.hpp, trace_wide_bvh.inc)
+  const bool wide = refill && (effFlags & YART_FLAG_WIDE_BVH) != 0;
+  auto pickExtend = [&]() -> void (*)(WfArgs) {
+    if (!refill) return ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
+    if (wide) return chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, true> : k_wf_extend_lean<TRAV_FAST | TRAV_WIDE, true>)
+                             : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, false> : k_wf_extend_lean<TRAV_FAST | TRAV_WIDE, false>);
+    return chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_extend_lean<TRAV_FAST, true>)
+                   : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_extend_lean<TRAV_FAST, false>);
+  };
+  auto pickShadow = [&]() -> void (*)(WfArgs) {
+    if (!refill) return ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>;
+    if (wide) return chunked ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, true> : k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE, true>)
+                             : (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, false> : k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE, false>);
+    return chunked ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_shadow_lean<TRAV_FAST, true>)
+                   : (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_shadow_lean<TRAV_FAST, false>);
+  };
+  auto kExtendFast = pickExtend();
+  auto kShadowFast = pickShadow();
   auto kRetryE = chunked ? k_wf_extend_retry_lean<true> : k_wf_extend_retry_lean<false>;
   auto kRetryS = chunked ? k_wf_shadow_retry_lean<true> : k_wf_shadow_retry_lean<false>;
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);

@@ -22,6 +22,9 @@ for rep in range(2):
         img, st = ds.render(p, flags=f)
         if ref is None:
             ref = img
-        same = bool((img.view("u4") == ref.view("u4")).all())
+        import numpy as np
+        frac = float(np.mean(np.all(img.view("u4") == ref.view("u4"), axis=-1)))
+        rm = float(np.sqrt(np.mean((np.nan_to_num(img[..., :3]).astype("f8") - np.nan_to_num(ref[..., :3])) ** 2)))
+        same = f"{frac:.6f} (rmse {rm:.2e})"
         print(f"flags={f} rep={rep} total={st['ms_device']:8.1f} ms  extend={st['ms_extend']:7.1f} connect={st['ms_connect']:7.1f} "
               f"shade={st['ms_shade']:7.1f} gmon={st['ms_gmon']:5.1f}  Msamples/s={w*h*spp/st['ms_device']*1e-3:7.1f} identical={same}", flush=True)

@@ -472,16 +472,17 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const bool chunked = s.host.nodes.size() >= 64;
   // TRAV_WIDE: the lean kernels walk the 4-wide records (wide_bvh.hpp, trace_wide_bvh.inc)
   const bool wide = refill && (effFlags & YART_FLAG_WIDE_BVH) != 0;
+  const bool wideE = wide && !(effFlags & 512u), wideS = wide && !(effFlags & 256u);   // (debug: 256 = closest-hit rays only, 512 = shadow rays only)
   auto pickExtend = [&]() -> void (*)(WfArgs) {
     if (!refill) return ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
-    if (wide) return chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, true> : k_wf_extend_lean<TRAV_FAST | TRAV_WIDE, true>)
+    if (wideE) return chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, true> : k_wf_extend_lean<TRAV_FAST | TRAV_WIDE, true>)
                              : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, false> : k_wf_extend_lean<TRAV_FAST | TRAV_WIDE, false>);
     return chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_extend_lean<TRAV_FAST, true>)
                    : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_extend_lean<TRAV_FAST, false>);
   };
   auto pickShadow = [&]() -> void (*)(WfArgs) {
     if (!refill) return ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>;
-    if (wide) return chunked ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, true> : k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE, true>)
+    if (wideS) return chunked ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, true> : k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE, true>)
                              : (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, false> : k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE, false>);
     return chunked ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_shadow_lean<TRAV_FAST, true>)
                    : (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_shadow_lean<TRAV_FAST, false>);

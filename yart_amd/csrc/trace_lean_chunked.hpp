@@ -54,6 +54,8 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
   // MODE & TRAV_WIDE (trace_wide_bvh.inc): cursor into the mesh's 4-wide records, their base, the interval end on entering the mesh
   uint32_t wideCur = 0, wideBase = 0;
   float tEntry = 0.0f;
+  // YART_LEAN_LOOP == 3 (trace_lean_bvh3.inc): the leaf a lane has put aside, its entry distance, "the stack ran empty after it"
+  uint32_t pendLink = 0; float pendD = 0.0f; bool pendExhausted = false;
   // Scene nodes this ray can reach at all, 64 at a time: bit k of `cand` = node candBase + k, set if its
   // padded world box and those of all its ancestors are hit within [0, hit.t] (conservative, see
   // traverseScene). Built by one wave-uniform pass over the chunk's node boxes; a missed node's subtree
@@ -177,6 +179,7 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
+                  pendLink = 0; pendExhausted = false;
                   if (MODE & TRAV_WIDE) { wideCur = root.leftFirst & kLinkAlphaBit; wideBase = mesh.wideOffset; tEntry = hit.t; }
                 }
               }
@@ -193,7 +196,9 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
     if constexpr ((MODE & TRAV_WIDE) != 0) {
 #include "trace_wide_bvh.inc"
     } else {
-#if YART_LEAN_LOOP == 2
+#if YART_LEAN_LOOP == 3
+#include "trace_lean_bvh3.inc"
+#elif YART_LEAN_LOOP == 2
 #include "trace_lean_bvh2.inc"
 #else
 #include "trace_lean_bvh.inc"
@@ -201,7 +206,7 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
     }
   }
 #undef LEAN_VISIT
-  (void)meshHasAlpha; (void)wideCur; (void)wideBase; (void)tEntry;
+  (void)meshHasAlpha; (void)wideCur; (void)wideBase; (void)tEntry; (void)pendLink; (void)pendD; (void)pendExhausted;
 #if defined(YART_COUNT_TRAVERSAL)
   tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
 #else

@@ -275,7 +275,11 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
     if (q.accRoughness > 0.5f) fl |= WF_REGULARIZED;
     p.flags = fl;
   }
+#if defined(YART_EXP_SKIP_NEE)      // timing experiment only (wrong frames): the shade kernel without its NEE block
+  const bool nee = false;
+#else
   const bool nee = !(res.scatter & (SC_EMITTED | SC_SPECULAR));
+#endif
 
   bool shadow = false;
   if (nee) {                                                    // L += attenuation * Ld(...)   (:79-80)

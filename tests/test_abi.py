@@ -79,3 +79,24 @@ def test_cpp_mirror_header_compiles_and_links(built, tmp_path):
     subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + lib_dir, "-lyart_hip",
                     "-Wl,-rpath," + lib_dir, "-lpthread"], check=True)
     assert subprocess.run([exe]).returncode == 0
+
+
+def test_crafted_scene_files_are_refused(built, tmp_path):
+    """.yscn loader (csrc/scene_file.hpp): sizes come from the file, so products of header fields are bounded before they
+    are formed and every read is checked against what is left of the file — a header whose width * height * channels wraps
+    to a small number must not get through."""
+    import struct
+    from yart_amd import api
+    L = api.lib()
+    head = b"YSCN0001" + struct.pack("<8I", 1, 0, 0, 0, 0, 0, 0, 0)
+    cases = {"wrapping texture size": head + struct.pack("<5I", 0x80000001, 0x80000001, 4, 0, 0) + b"\0" * 64,
+             "five channels": head + struct.pack("<5I", 4, 4, 5, 0, 0) + b"\0" * 128,
+             "truncated texel data": head + struct.pack("<5I", 64, 64, 4, 0, 0) + b"\0" * 100,
+             "huge mesh": b"YSCN0001" + struct.pack("<8I", 0, 0, 1, 0, 0, 0, 0, 0) + struct.pack("<2I", 0xffffffff, 0xffffffff),
+             "not a scene": b"GARBAGE!" + b"\0" * 64}
+    for name, blob in cases.items():
+        path = os.path.join(tmp_path, "bad.yscn")
+        with open(path, "wb") as f:
+            f.write(blob)
+        h = ctypes.c_void_p()
+        assert L.yart_hip_scene_load(path.encode(), 0, ctypes.byref(h)) == api.YART_E_IO, name

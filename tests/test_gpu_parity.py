@@ -89,7 +89,9 @@ def test_per_sample_radiance_vs_reference(api, case):
     exact = np.all(got.view(np.uint32) == ref.view(np.uint32), axis=1).mean()
     close = np.all(np.isclose(got, ref, rtol=1e-4, atol=1e-5, equal_nan=True), axis=1).mean()
     print(f"{case}: samples bit-identical {exact:.3f}, within 1e-4 {close:.3f}, rays {rays} vs {kat['probe_rays'][0]}")
-    assert close > 0.97, "more than 3% of the probe samples took a different path"
+    # with glibc's libm algorithms on the device every sample is the reference's bit for bit on this pool; should a box select
+    # other libm variants the frames drift to the 1e-8 regime and this is the first test to say so
+    assert exact > 0.99 and close > 0.999, "probe samples differ from the reference's"
     assert abs(rays - kat["probe_rays"][0]) <= max(4, 0.01 * kat["probe_rays"][0])
     scene.close()
 

@@ -37,6 +37,7 @@ inline std::unique_ptr<LoadedScene> loadSceneFile(const std::string& path) {
   std::vector<uint8_t> file;
   std::fseek(f, 0, SEEK_END);
   long sz = std::ftell(f);
+  if (sz < 0) { std::fclose(f); throw std::runtime_error("cannot size scene file " + path); }
   std::fseek(f, 0, SEEK_SET);
   file.resize(size_t(sz));
   size_t got = std::fread(file.data(), 1, file.size(), f);
@@ -44,7 +45,8 @@ inline std::unique_ptr<LoadedScene> loadSceneFile(const std::string& path) {
   if (got != file.size()) throw std::runtime_error("short read on " + path);
 
   size_t pos = 0;
-  auto need = [&](size_t n) { if (pos + n > file.size()) throw std::runtime_error("truncated scene file"); };
+  // every size below comes from the file: compared without forming pos + n (which could wrap)
+  auto need = [&](size_t n) { if (pos > file.size() || n > file.size() - pos) throw std::runtime_error("truncated scene file"); };
   auto u32 = [&]() { need(4); uint32_t v; std::memcpy(&v, &file[pos], 4); pos += 4; return v; };
   auto s = std::make_unique<LoadedScene>();
   auto blob = [&](size_t bytes) -> const void* {
@@ -61,6 +63,9 @@ inline std::unique_ptr<LoadedScene> loadSceneFile(const std::string& path) {
   for (uint32_t i = 0; i < nt; i++) {
     YartTextureDesc t{};
     t.width = u32(); t.height = u32(); t.channels = u32(); t.is_float = u32(); t.type = u32();
+    // bounded before they are multiplied: a crafted header must not wrap the product into a small blob that passes need()
+    if (t.width == 0 || t.height == 0 || t.width > (1u << 16) || t.height > (1u << 16) || t.channels == 0 || t.channels > 4)
+      throw std::runtime_error("scene file: texture dimensions out of range");
     t.data = blob(size_t(t.width) * t.height * t.channels * (t.is_float ? 4 : 1));
     s->textures.push_back(t);
   }
@@ -74,6 +79,7 @@ inline std::unique_ptr<LoadedScene> loadSceneFile(const std::string& path) {
   for (uint32_t i = 0; i < nme; i++) {
     YartMeshDesc m{};
     m.n_vertices = u32(); m.n_faces = u32();
+    if (m.n_vertices > (1u << 28) || m.n_faces > (1u << 28)) throw std::runtime_error("scene file: mesh size out of range");
     m.positions = static_cast<const float*>(blob(size_t(m.n_vertices) * 12));
     m.normals = static_cast<const float*>(blob(size_t(m.n_vertices) * 12));
     m.tangents = static_cast<const float*>(blob(size_t(m.n_vertices) * 16));
@@ -120,7 +126,9 @@ inline void saveSceneFile(const YartSceneDesc& d, const std::string& path) {
     u32(m.n_vertices); u32(m.n_faces);
     arr(m.positions, size_t(m.n_vertices) * 12); arr(m.normals, size_t(m.n_vertices) * 12);
     arr(m.tangents, size_t(m.n_vertices) * 16); arr(m.uvs, size_t(m.n_vertices) * 8);
-    arr(m.faces, size_t(m.n_faces) * 16); arr(m.face_light, size_t(m.n_faces) * 4);
+    arr(m.faces, size_t(m.n_faces) * 16);
+    if (m.face_light) arr(m.face_light, size_t(m.n_faces) * 4);
+    else { const std::vector<int32_t> none(m.n_faces, -1); arr(none.data(), size_t(m.n_faces) * 4); }   // the ABI allows NULL: no lights
   }
   for (uint32_t i = 0; i < d.n_nodes; i++) put(&d.nodes[i], sizeof(YartNodeDesc));
   for (uint32_t i = 0; i < d.n_lights; i++) put(&d.lights[i], sizeof(YartLightDesc));

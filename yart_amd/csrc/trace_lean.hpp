@@ -39,6 +39,11 @@ constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;   // leave the inner loo
 #define YART_LEAN_LOOP 2
 #endif
 
+// lean kernels evaluate an alpha-tested candidate's texture alpha themselves and hand the ray over only where it is not opaque
+#ifndef YART_LEAN_ALPHA_PEEK
+#define YART_LEAN_ALPHA_PEEK 0
+#endif
+
 struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general variant only (alpha tests)
 
 // Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)

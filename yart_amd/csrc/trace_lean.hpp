@@ -44,6 +44,11 @@ constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;   // leave the inner loo
 #define YART_LEAN_ALPHA_PEEK 0
 #endif
 
+// inner step: node-pair loads and box tests in one predicated region (1) or unconditional with pop-only lanes reading the root pair (0)
+#ifndef YART_LEAN_MASKED_LOADS
+#define YART_LEAN_MASKED_LOADS 0
+#endif
+
 struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general variant only (alpha tests)
 
 // Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)

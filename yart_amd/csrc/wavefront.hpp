@@ -22,7 +22,7 @@ struct WfState {
   // ray0 = {o.xyz, d.x}  ray1 = {d.yz, lastPdf, accRoughness}
   // thr0 = {att.xyz, L.x} thr1 = {L.yz, flags(u32), dim(u32)}
   // hit0 = {t, u, v, tri(u32)}  hit1 = {hit word (wfHitWord), morton.lo, morton.hi, sampler-table column (u32)}
-  // sh0 = {to.xyz, cosTerm}  sh1 = {attPre.xyz, denom}  sh2 = {Lif.xyz, lightIsArea}
+  // sh0 = {to.xyz, -}  sh1 = {attPre.xyz, denom}  sh2 = {Lif.xyz, cosTerm}   (k_wf_post reads sh1, sh2 only)
   f4 *ray0, *ray1, *thr0, *thr1, *hit0, *hit1, *sh0, *sh1, *sh2;
 };
 // exact test counters of the instrumented build (libyart_hip_count.so); empty otherwise
@@ -298,9 +298,9 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
         float pdfLight = pl * ls.pdf / absDot(ls.n, ls.wi);
         if (l.type == LIGHT_AREA) pdfLight *= length2(hit.p - ls.p);
         const f3 Lif = ls.Li * f;
-        wfSt(s.sh0 + i, mk4(ls.p.x, ls.p.y, ls.p.z, absDot(ls.wi, hit.n)));
+        wfSt(s.sh0 + i, mk4(ls.p.x, ls.p.y, ls.p.z, 0.0f));
         wfSt(s.sh1 + i, mk4(p.att.x, p.att.y, p.att.z, pdfBSDF + pdfLight));
-        wfSt(s.sh2 + i, mk4(Lif.x, Lif.y, Lif.z, 0.0f));
+        wfSt(s.sh2 + i, mk4(Lif.x, Lif.y, Lif.z, absDot(ls.wi, hit.n)));
         shadow = true;
       }
     }

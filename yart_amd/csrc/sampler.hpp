@@ -25,7 +25,16 @@ struct SamplerTables {
   const uint64_t* hash = nullptr;      // [dims + 3]
   const uint32_t* sobol1 = nullptr;    // [8][256]: XOR of the matrix columns selected by byte b of the index
   uint32_t dims = 0, stride = 0;
+  // Permutation rows of the sample digits BELOW the two the entry holds (round 2). Those digits were hashed per draw
+  // (one 64-bit mixBits each, ~50 instructions; two of them per draw at 256 spp: a quarter of the shade kernel). Level k
+  // stands for digit firstPixelDigit - 3 - k; its row depends on the pixel, the dimension and the 4 + 2k sample bits above
+  // the digit, so it has 16 * 4^k rows of one byte, at samplerRowOffset(k) inside the rowBytes of one (dimension, pixel).
+  // lastBit: the xor bit of an odd log2spp (sampler.hpp:168-171) for each of the 2^(log2spp - 1) sample prefixes, as bits
+  // after the rows.
+  const uint8_t* rows = nullptr;       // [dims][stride][rowBytes]
+  uint32_t rowBytes = 0, rowLevels = 0, lastBit = 0, lastBitOffset = 0;
 };
+YART_HD uint32_t samplerRowOffset(uint32_t level) { return (16u * ((1u << (2u * level)) - 1u)) / 3u; }   // 0, 16, 80, 336
 
 struct SamplerConfig {
   uint32_t log2spp;       // log2Int(float(spp)), math_base.hpp:156-160
@@ -150,6 +159,38 @@ YART_HD uint64_t getSampleIndexDirect(const Sampler& s, const SamplerConfig& c) 
 // lie entirely in the pixel bits (a digit never straddles: digitShift has the parity of log2spp).
 YART_HD int samplerFirstPixelDigit(const SamplerConfig& c) { return int((c.log2spp + 1u) / 2u); }
 
+// How many digit levels (and whether the last bit) fit `budget` bytes per (dimension, pixel); fills the layout fields of t.
+YART_HD void samplerRowLayout(const SamplerConfig& c, uint32_t budget, SamplerTables& t) {
+  const int lastDigit = int(c.log2spp & 1u);
+  const int remaining = samplerFirstPixelDigit(c) - 2 - lastDigit;      // sample digits below the entry's two
+  uint32_t levels = 0;
+  while (int(levels) < remaining && levels < 4u && samplerRowOffset(levels + 1u) <= budget) levels++;
+  uint32_t bytes = samplerRowOffset(levels);
+  t.rowLevels = levels; t.lastBit = 0; t.lastBitOffset = bytes;
+  if (lastDigit && int(levels) == (remaining > 0 ? remaining : 0) && c.log2spp >= 1u && c.log2spp <= 12u) {
+    const uint32_t bitBytes = ((1u << (c.log2spp - 1u)) + 7u) / 8u;
+    if (bytes + bitBytes <= budget) { t.lastBit = 1; bytes += bitBytes; }
+  }
+  t.rowBytes = (bytes + 3u) & ~3u;
+}
+// byte `b` of the rows of (pixelMorton, dim): what samplerRowLayout laid out
+YART_HD uint8_t samplerRowByte(const SamplerConfig& c, const SamplerTables& t, uint64_t pixelMorton, uint32_t dim, uint32_t b) {
+  const int lastDigit = int(c.log2spp & 1u);
+  const uint64_t dimMix = uint64_t(0x55555555u * dim);
+  if (b < t.lastBitOffset) {
+    uint32_t level = 0;
+    while (b >= samplerRowOffset(level + 1u)) level++;
+    const uint32_t prefix = b - samplerRowOffset(level), bits = 4u + 2u * level;
+    return uint8_t(permutationRowFor((pixelMorton << bits) | prefix, dimMix));
+  }
+  if (!t.lastBit || !lastDigit) return 0;
+  const uint32_t first = (b - t.lastBitOffset) * 8u, n = 1u << (c.log2spp - 1u);
+  uint32_t v = 0;
+  for (uint32_t k = 0; k < 8u && first + k < n; k++)
+    v |= uint32_t(mixBits(((pixelMorton << (c.log2spp - 1u)) | (first + k)) ^ dimMix) & 1ull) << k;
+  return uint8_t(v);
+}
+
 YART_HD uint64_t samplerTableEntry(const SamplerConfig& c, uint64_t pixelMorton, uint32_t dim) {
   const int lastDigit = int(c.log2spp & 1u);
   const uint64_t dimMix = uint64_t(0x55555555u * dim);
@@ -182,16 +223,32 @@ YART_HD uint64_t getSampleIndex(const Sampler& s, const SamplerConfig& c) {
       const uint32_t shift2 = shift - 2u;
       const uint32_t digit = uint32_t(s.morton >> shift2) & 3u;
       index |= uint64_t((uint32_t(e >> (32u + 8u * top)) >> (2u * digit)) & 3u) << shift2;
-      for (--i; i >= lastDigit; i--) {                          // remaining digits: direct
+#if defined(YART_EXP_SKIP_LOW_DIGITS)     // timing experiment only (wrong samples): what the directly hashed digits cost
+      i = lastDigit - 1;
+#endif
+      const uint8_t* rows = c.tab.rows ? c.tab.rows + (size_t(s.dim) * c.tab.stride + s.pix) * c.tab.rowBytes : nullptr;
+      uint32_t level = 0;
+      for (--i; i >= lastDigit; i--, level++) {                 // remaining digits: from the row table, else hashed
         const uint32_t digitShift = uint32_t(2 * i - lastDigit);
         const uint32_t dg = uint32_t(s.morton >> digitShift) & 3u;
-        index |= uint64_t((permutationRowFor(s.morton >> (digitShift + 2), dimMix) >> (2u * dg)) & 3u) << digitShift;
+        uint32_t row;
+        if (rows != nullptr && level < c.tab.rowLevels) {
+          const uint32_t prefix = uint32_t(s.morton >> (digitShift + 2u)) & ((1u << (4u + 2u * level)) - 1u);
+          row = rows[samplerRowOffset(level) + prefix];
+        } else row = permutationRowFor(s.morton >> (digitShift + 2), dimMix);
+        index |= uint64_t((row >> (2u * dg)) & 3u) << digitShift;
       }
     }
   }
   if (lastDigit) {
     const uint32_t digit = uint32_t(s.morton & 1ull);
-    index |= uint64_t(digit ^ uint32_t(mixBits((s.morton >> 1) ^ dimMix) & 1ull));
+    uint32_t mix;
+    if (c.tab.rows != nullptr && c.tab.lastBit) {
+      const uint32_t prefix = uint32_t(s.morton >> 1) & ((1u << (c.log2spp - 1u)) - 1u);
+      const uint8_t* rows = c.tab.rows + (size_t(s.dim) * c.tab.stride + s.pix) * c.tab.rowBytes;
+      mix = (uint32_t(rows[c.tab.lastBitOffset + (prefix >> 3)]) >> (prefix & 7u)) & 1u;
+    } else mix = uint32_t(mixBits((s.morton >> 1) ^ dimMix) & 1ull);
+    index |= uint64_t(digit ^ mix);
   }
   return index;
 }

@@ -39,6 +39,7 @@ FLAG_NO_REFILL = 16
 FLAG_NO_COMPACTION = 32
 FLAG_NO_SHADE_SORT = 64
 FLAG_WIDE_BVH = 128
+FLAG_SAMPLER_ROWS = 1024
 
 
 class YartError(RuntimeError):

@@ -34,7 +34,7 @@ def api(built):
 
 PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+shade_sort": 2, "wavefront+general_trace": 4,
                   "wavefront+direct_sampler": 8, "wavefront+no_refill": 16, "wavefront+no_compaction": 32,
-                  "wavefront+no_shade_sort": 64, "wavefront+wide_bvh": 128, "wavefront+sampler_rows": 1024}
+                  "wavefront+no_shade_sort": 64, "wavefront+wide_bvh": 128}
 
 
 @pytest.mark.parametrize("pipeline", list(PIPELINE_FLAGS))

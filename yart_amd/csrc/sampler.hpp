@@ -20,6 +20,15 @@ namespace yart_hip {
 // plus hashDim(d) for d <= dims, and byte-wise XOR tables of the Sobol' dimension-1 matrix.
 // A draw then costs 2 table reads + the remaining (spp-dependent) low digits instead of
 // nBase4Digits 64-bit hash evaluations. Dimensions >= dims fall back to the direct evaluation.
+// 1: the per-draw code can read the rows of the low sample digits (YART_FLAG_SAMPLER_ROWS); 0: compiled out — the default,
+// because the mere presence of that path costs the shade kernel 12 ms per C3 frame (442 -> 454 ms shade stage) with the flag off
+#ifndef YART_SAMPLER_ROWS
+#if defined(__HIPCC__)
+#define YART_SAMPLER_ROWS 0
+#else
+#define YART_SAMPLER_ROWS 1      // host builds (tests/hostsim selftest) keep it: table form == direct form, every budget
+#endif
+#endif
 struct SamplerTables {
   const uint64_t* entries = nullptr;   // [dims][stride]
   const uint64_t* hash = nullptr;      // [dims + 3]
@@ -226,7 +235,11 @@ YART_HD uint64_t getSampleIndex(const Sampler& s, const SamplerConfig& c) {
 #if defined(YART_EXP_SKIP_LOW_DIGITS)     // timing experiment only (wrong samples): what the directly hashed digits cost
       i = lastDigit - 1;
 #endif
+#if YART_SAMPLER_ROWS
       const uint8_t* rows = c.tab.rows ? c.tab.rows + (size_t(s.dim) * c.tab.stride + s.pix) * c.tab.rowBytes : nullptr;
+#else
+      const uint8_t* rows = nullptr;
+#endif
       uint32_t level = 0;
       for (--i; i >= lastDigit; i--, level++) {                 // remaining digits: from the row table, else hashed
         const uint32_t digitShift = uint32_t(2 * i - lastDigit);
@@ -243,7 +256,7 @@ YART_HD uint64_t getSampleIndex(const Sampler& s, const SamplerConfig& c) {
   if (lastDigit) {
     const uint32_t digit = uint32_t(s.morton & 1ull);
     uint32_t mix;
-    if (c.tab.rows != nullptr && c.tab.lastBit) {
+    if (YART_SAMPLER_ROWS && c.tab.rows != nullptr && c.tab.lastBit) {
       const uint32_t prefix = uint32_t(s.morton >> 1) & ((1u << (c.log2spp - 1u)) - 1u);
       const uint8_t* rows = c.tab.rows + (size_t(s.dim) * c.tab.stride + s.pix) * c.tab.rowBytes;
       mix = (uint32_t(rows[c.tab.lastBitOffset + (prefix >> 3)]) >> (prefix & 7u)) & 1u;

@@ -558,7 +558,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     ta.cfg = rc.sampler; ta.pixels = s.pixels.p; ta.nPixels = nPix; ta.dims = dims;
     ta.entries = s.smpEntries.p; ta.hash = s.smpHash.p; ta.sobol1 = s.smpSobol1.p;
     // rows of the sample digits below the entry's two: as many levels as 1/16 of the device memory holds for these dimensions and pixels
-    if (effFlags & YART_FLAG_SAMPLER_ROWS) {
+    if ((effFlags & YART_FLAG_SAMPLER_ROWS) && YART_SAMPLER_ROWS) {
       const uint64_t budget = uint64_t(totalB) / 16u / (uint64_t(dims) * nPix);
       samplerRowLayout(rc.sampler, uint32_t(std::min<uint64_t>(budget, 4096u)), ta.cfg.tab);
       if (ta.cfg.tab.rowBytes != 0u) {

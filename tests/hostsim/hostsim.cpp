@@ -355,6 +355,15 @@ static int doSelfTest() {
       }
     }
   }
+  // v % 24 of the permutation-row selection: the multiply-free form against the operator, random and edge 40-bit values
+  for (uint64_t k = 0; k < 400000; k++) {
+    uint64_t v = (uint64_t(rng.next()) << 8 | (rng.next() & 0xffu)) & 0xffffffffffull;
+    if (k < 64) v = k;
+    else if (k < 128) v = 0xffffffffffull - (k - 64);
+    else if (k < 192) v = (1ull << (k - 128 < 40 ? k - 128 : 39)) - (k & 1);
+    if (mod24of40(v) != uint32_t(v % 24ull)) { std::fprintf(stderr, "selftest: mod24of40(%llu)\n", (unsigned long long) v); return 3; }
+    checked++;
+  }
   // CDF search
   for (uint32_t n : {1u, 2u, 3u, 7u, 64u, 100u, 1000u}) {
     for (int kind = 0; kind < 4; kind++) {

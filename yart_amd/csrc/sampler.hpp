@@ -140,9 +140,18 @@ YART_HD void startPixelSample(Sampler& s, const SamplerConfig& c, uint32_t px, u
   s.morton = (encodeMorton2(px, py) << c.log2spp) | uint64_t(sample);
 }
 
+// v % 24 for a 40-bit v (mixBits(...) >> 24) without a 64-bit magic-number multiply (four quarter-rate 32-bit multiplies on
+// CDNA): v = 8 q + (v & 7) and 24 = 8 * 3, so v % 24 = 8 (q % 3) + (v & 7); 2^24 = 1 (mod 3) folds the 37-bit q to 25 bits,
+// whose remainder by 3 is one 32-bit multiply-high. Checked against % 24 by hostsim selftest.
+YART_HD uint32_t mod24of40(uint64_t v) {
+  const uint64_t q = v >> 3;
+  const uint32_t a = uint32_t(q & 0xffffffull) + uint32_t(q >> 24);       // < 2^24 + 2^13, same residue mod 3
+  const uint32_t t = uint32_t((uint64_t(a) * 0xAAAAAAABull) >> 33);      // a / 3
+  return 8u * (a - 3u * t) + (uint32_t(v) & 7u);
+}
 // one digit of the permutation: row of permutations[][] for the digit whose higher digits are `higher`
 YART_HD uint32_t permutationRowFor(uint64_t higher, uint64_t dimMix) {
-  return permutationRow(uint32_t((mixBits(higher ^ dimMix) >> 24) % 24ull));
+  return permutationRow(mod24of40(mixBits(higher ^ dimMix) >> 24));
 }
 
 YART_HD uint64_t getSampleIndexDirect(const Sampler& s, const SamplerConfig& c) {   // sampler.hpp:155-173

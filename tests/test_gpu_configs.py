@@ -103,6 +103,16 @@ def test_c5_full_detail_window_of_the_4k_frame(api, tmp_path):
         assert st["samples"] == info["pixels"] * 512
         same, e = _compare(img, ref, f"mclaren_class 4K x 512 spp, {info['pixels']} pixels / {name}")
         assert e < RMSE_TOL and same > 0.99, name
+    # the WHOLE job on one GPU (8.3 M pixels x 512 spp = 4.25 G paths: several batches of what the memory holds, 1 GiB paths
+    # at most): every pixel finite with alpha 1, and the window's pixels are still the oracle's
+    full, st = scene.render(p)
+    assert st["samples"] == 3840 * 2160 * 512
+    assert np.isfinite(full).all() and np.all(full[..., 3] == 1.0)
+    mask = ref[..., 3] == 1.0
+    same = float(np.mean(np.all(full[mask].view(np.uint32) == ref[mask].view(np.uint32), axis=-1)))
+    print(f"mclaren_class 3840x2160x512 full frame: {3840 * 2160 * 512 / st['ms_device'] * 1e-3:.1f} Msamples/s, "
+          f"{st['ms_device'] / 1e3:.2f} s, window pixels identical {same:.5f}")
+    assert same > 0.99
     scene.close()
 
 

@@ -83,6 +83,18 @@ def test_c4_1024spp_window_of_the_full_frame(api, tmp_path):
     assert e < RMSE_TOL and same > 0.99
     mega, _ = scene.render(q, rank=shard[0], world_size=shard[1], flags=PIPELINE_FLAGS["megakernel"])
     assert np.array_equal(mega.view(np.uint32), img.view(np.uint32))
+    # the whole C4 frame on one GPU (2.12 G paths, several batches), and as the 8 ranks of the BASELINE configuration
+    # dealt 16-pixel blocks: the window's pixels are the oracle's either way, the 8 shares are disjoint and complete
+    full, st = scene.render(p)
+    assert st["samples"] == 1920 * 1080 * 1024 and np.isfinite(full).all()
+    mask = ref[..., 3] == 1.0
+    assert np.mean(np.all(full[mask].view(np.uint32) == ref[mask].view(np.uint32), axis=-1)) > 0.99
+    print(f"sponza_class 1920x1080x1024 full frame: {1920 * 1080 * 1024 / st['ms_device'] * 1e-3:.1f} Msamples/s")
+    acc = np.zeros_like(full)
+    for r in range(8):
+        part, _ = scene.render(dict(p, shard_tile=16), rank=r, world_size=8)
+        acc += part
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
     scene.close()
 
 

@@ -1,0 +1,39 @@
+"""The device headers and the host side of the library (scene build, .yscn loader, wide records, sampler tables) compiled for
+the host with AddressSanitizer + UndefinedBehaviorSanitizer (GPU sanitizers are not available on the pool: the CPU build is
+where they run). The binary is tests/hostsim with -fsanitize=address,undefined; it must stay clean on the self test, the wide
+record check, the BVH build check and a golden render — and the render must still be the reference's frame bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN, ROOT
+
+SAN = os.path.join(ROOT, "tests", "hostsim", "_build", "hostsim_san")
+SRC = [os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp"), os.path.join(ROOT, "yart_amd", "csrc", "_gen", "lut_data.cpp")]
+
+
+@pytest.fixture(scope="module")
+def san(built):
+    newest = max(os.path.getmtime(os.path.join(dp, f)) for d in ("yart_amd/csrc", "tests/hostsim", "oracle")
+                 for dp, _, fs in os.walk(os.path.join(ROOT, d)) for f in fs if f.endswith((".hpp", ".cpp", ".inc")))
+    if not os.path.exists(SAN) or os.path.getmtime(SAN) < newest:
+        r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-ffp-contract=off", "-o", SAN] + SRC + ["-lpthread"], capture_output=True, text=True)
+        if r.returncode != 0:
+            pytest.skip("no sanitizer runtime for g++ here: " + r.stderr[-200:])
+    return SAN
+
+
+def test_host_build_is_clean_under_asan_and_ubsan(san, tmp_path):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    for args in (["selftest"], ["widecheck", os.path.join(GOLDEN, "material.yscn"), "4000"],
+                 ["bvhcheck", os.path.join(GOLDEN, "material.yscn"), "3"]):
+        r = subprocess.run([san] + args, capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, (args, r.stderr[-800:])
+    out = os.path.join(tmp_path, "m.f32")
+    base = os.path.join(GOLDEN, "material")
+    r = subprocess.run([san, "render", base + ".yscn", base + ".txt", out], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-800:]
+    assert np.array_equal(np.fromfile(out, np.uint32), np.fromfile(base + ".f32", np.uint32))

@@ -29,6 +29,7 @@ import glob
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -107,10 +108,23 @@ def pmc_traffic(args):
                    sys.executable or "python3", os.path.join(ROOT, "bench.py"), "--pmc-child",
                    "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--depth", str(args.depth),
                    "--tex", str(args.tex), "--sky", str(args.sky), "--flags", str(args.flags)]
+            # its own process group: should the pass hang, the profiler AND the python under it are ended together
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
-            except (OSError, subprocess.TimeoutExpired):
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                        start_new_session=True)
+            except OSError:
                 return None
+            try:
+                so, se = proc.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                sys.stderr.write(f"bench.py: rocprofv3 --pmc {counter} pass did not finish in 240 s; traffic = null\n")
+                return None
+            r = subprocess.CompletedProcess(cmd, proc.returncode, so, se)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 sys.stderr.write(f"bench.py: rocprofv3 --pmc {counter} pass failed ({r.returncode}): {r.stderr.strip()[-300:]}\n")

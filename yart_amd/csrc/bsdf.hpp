@@ -645,16 +645,24 @@ YART_HD BsdfSample bsdfSampleImplE(const SceneDev& sc, const MaterialDev& mt, Ma
     e.cr = roughen(e.cr);
   }
   GGX mfCoat = makeGGX(e.cr);
-  f3 wmCoat = ggxSampleVisibleMicrofacet(mfCoat, _wo, u);
-  const float Favg = FavgFit(1.5f);
-  const float Eavg = ggxEavg(sc.lut, e.cr);
-  const float Fms = Favg * Favg * Eavg / (1.0f - Favg * (1.0f - Eavg));
-  const float E_o = ggxE(sc.lut, absDot(_wo, wmCoat), e.cr);
-  const float kappa = 1.0f - (Favg * E_o + Fms * (1.0f - E_o));
-  // "c * (1.0 - kappa)" is evaluated in double (parametric.cpp:221)
-  const float pClearcoat = float(double(e.c) * (1.0 - double(kappa)));
-  const float pMetallic = (1.0f - pClearcoat) * e.m;
-  const float pDielectric = (1.0f - pClearcoat) * (e.m + (1.0f - e.m) * e.t);
+  // The reference computes the clearcoat selection probability for every hit (parametric.cpp:205-224: a visible-normal
+  // sample, two LUT lookups, kappa). With c = m = t = 0 — a material without clearcoat, metal or transmission, the bulk of
+  // most scenes — it cannot matter: pClearcoat = 0 * (1 - kappa) is +-0 (or NaN), pMetallic and pDielectric are that times 0,
+  // and `uc2 < p` is false for all three whatever kappa was; the glossy-diffuse lobe is sampled. Skipping the computation
+  // there leaves every result as it is (the shade kernel spends ~a fifth of its instructions on it otherwise).
+  float pClearcoat = 0.0f, pMetallic = 0.0f, pDielectric = 0.0f;
+  if (!(e.c == 0.0f && e.m == 0.0f && e.t == 0.0f)) {
+    f3 wmCoat = ggxSampleVisibleMicrofacet(mfCoat, _wo, u);
+    const float Favg = FavgFit(1.5f);
+    const float Eavg = ggxEavg(sc.lut, e.cr);
+    const float Fms = Favg * Favg * Eavg / (1.0f - Favg * (1.0f - Eavg));
+    const float E_o = ggxE(sc.lut, absDot(_wo, wmCoat), e.cr);
+    const float kappa = 1.0f - (Favg * E_o + Fms * (1.0f - E_o));
+    // "c * (1.0 - kappa)" is evaluated in double (parametric.cpp:221)
+    pClearcoat = float(double(e.c) * (1.0 - double(kappa)));
+    pMetallic = (1.0f - pClearcoat) * e.m;
+    pDielectric = (1.0f - pClearcoat) * (e.m + (1.0f - e.m) * e.t);
+  }
   BsdfSample s;
   if (uc2 < pClearcoat) {
     s = sampleClearcoat(mt, _wo, mfCoat, u);

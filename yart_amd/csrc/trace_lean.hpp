@@ -90,7 +90,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
   // YART_LEAN_LOOP == 3 (trace_lean_bvh3.inc): the leaf a lane has put aside, its entry distance, "the stack ran empty after it"
   uint32_t pendLink = 0; float pendD = 0.0f; bool pendExhausted = false;
   // scene nodes this ray can reach at all: bit n survives if the padded world box of n and of all
-  // its ancestors is hit within [0, tMax] (conservative, see traverseScene); requires nNodes <= 64
+  // its ancestors is hit within [0, tMax] (conservative, see traverseScene); used for scenes of fewer than 64 nodes (the all-ones mask marks a new ray)
   unsigned long long cand = 0;
 #if defined(YART_COUNT_TRAVERSAL)
   AlphaCtx actx; actx.sampler = nullptr;     // only its counters are used (YART_COUNT)

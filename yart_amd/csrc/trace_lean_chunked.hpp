@@ -1,4 +1,4 @@
-// trace_lean_chunked.hpp — trace_lean.hpp for scenes of more than 64 nodes (device only).
+// trace_lean_chunked.hpp — trace_lean.hpp for scenes of 64 nodes and more (device only).
 //
 // Same algorithm; the per-ray scene-node candidate mask covers 64 nodes at a time (candBase), rebuilt when
 // the walk moves on to the next chunk, and a missed node's subtree is jumped over through its skip link.

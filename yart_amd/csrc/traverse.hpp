@@ -412,7 +412,9 @@ YART_HD Hit finalizeHit(const SceneDev& sc, const HitRec& r, f3 o, f3 d) {
   h.p = oo + (r.t * od);                                   // ray(t), ray.hpp:27-29
   h.backSide = (r.backSide & 1u) != 0;
   const ShadeTri& st = sc.shadeTris[mesh.triOffset + r.tri];
-  h.material = st.material;
+  // the material index travels with the hit (every traversal variant packs it above the back-side bit): the material
+  // record is fetched without waiting for the triangle's shade record
+  h.material = r.backSide >> 1;
   const MaterialDev& mt = sc.materials[h.material];
   // testMesh: tangents with barycentrics (w,u,v), normal map, tangent rebuilt from n x Y
   const float w = 1.0f - r.u - r.v;

@@ -233,7 +233,8 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
     return WF_TERMINATED;
   }
   HitRec hr;
-  hr.t = h0.x; hr.u = h0.y; hr.v = h0.z; hr.tri = asU(h0.w); hr.node = nodeBack & ((1u << kWfNodeBits) - 1u); hr.backSide = nodeBack >> 31;
+  hr.t = h0.x; hr.u = h0.y; hr.v = h0.z; hr.tri = asU(h0.w); hr.node = nodeBack & ((1u << kWfNodeBits) - 1u);
+  hr.backSide = (nodeBack >> 31) | (((nodeBack >> kWfNodeBits) & kWfClassMiss) << 1);
   Hit hit = finalizeHit(sc, hr, p.o, p.d);
   WF_TALLY_SHADE(tally);
   const MaterialDev& mt = sc.materials[hit.material];

@@ -273,6 +273,10 @@ int yart_hip_multi_create(const YartSceneDesc* desc, const int* devices, uint32_
 int yart_hip_multi_load(const char* path, const YartImportOptions* opts, const int* devices, uint32_t n_devices, YartMulti** out);
 void yart_hip_multi_destroy(YartMulti* multi);
 int yart_hip_multi_device_count(const YartMulti* multi);
+/* Diagnostic: the RCCL calls of the merge (ncclCommInitAll, one group of ncclSend + ncclRecv on a stream, ncclCommDestroy) on a
+ * one-rank communicator of `device` — the rank sends a slab of n_floats to itself and compares. Shows on a one-GPU box that
+ * RCCL is linked, initialises and moves a slab; YART_E_RCCL otherwise. */
+int yart_hip_multi_rccl_selftest(int device, uint32_t n_floats);
 /* stats: samples / rays / test counters summed over the devices, ms_* the slowest device's, ms_total the call's wall time */
 int yart_hip_multi_render(YartMulti* multi, const YartCameraDesc* cam, const YartRenderParams* params, float* out_rgba,
                           YartStats* stats);

@@ -6,6 +6,7 @@ records against the device traversal.
 Windows of a frame: the library renders only the pixel blocks of rank r of N (YartRenderParams.rank / world_size /
 shard_tile); the oracle restatement takes the same three numbers (oracle/params.hpp shard_*), so a full-size camera
 and sampler state is checked on a few thousand pixels scattered over the frame in seconds."""
+import ctypes
 import json
 import os
 import subprocess
@@ -244,3 +245,12 @@ def test_multi_device_entry_equals_single_device(api):
     got1, _ = one.render(p)
     assert np.array_equal(got1.view(np.uint32), want.view(np.uint32))
     one.close(); single.close()
+
+
+def test_rccl_calls_of_the_merge_run_on_this_box(api):
+    """yart_hip_multi_rccl_selftest: ncclCommInitAll + a grouped ncclSend / ncclRecv of a 4 MB slab (one rank, to itself) +
+    ncclCommDestroy through the library — the transport calls of the multi-device merge, which otherwise need two GPUs."""
+    L = api.lib()
+    L.yart_hip_multi_rccl_selftest.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    rc = L.yart_hip_multi_rccl_selftest(0, 1 << 20)
+    assert rc == 0, (rc, L.yart_hip_last_error())

@@ -951,6 +951,40 @@ int yart_hip_multi_load(const char* path, const YartImportOptions* opts, const i
 
 void yart_hip_multi_destroy(YartMulti* multi) { delete multi; }
 
+int yart_hip_multi_rccl_selftest(int device, uint32_t n_floats) {
+  return guarded([&] {
+    require(n_floats > 0 && n_floats <= (1u << 26), "n_floats out of range");
+    const int dev = resolveDevice(device);
+    if (dev < 0) throw HipError("no usable HIP device (libyart_hip has no CPU fallback)");
+    HIP_CHECK(hipSetDevice(dev));
+    // the calls of mergeSlabs on a one-rank communicator: the rank sends a slab to itself (matching send / recv in one group)
+    ncclComm_t comm = nullptr;
+    RCCL_CHECK(ncclCommInitAll(&comm, 1, &dev));
+    hipStream_t st = nullptr;
+    DevBuf<float> a, b;
+    std::vector<float> h(n_floats), back(n_floats, 0.0f);
+    for (uint32_t i = 0; i < n_floats; i++) h[i] = float(i % 8191u) * 0.25f - 3.0f;
+    try {
+      HIP_CHECK(hipStreamCreate(&st));
+      a.upload(h); b.ensure(n_floats);
+      HIP_CHECK(hipMemsetAsync(b.p, 0, size_t(n_floats) * 4, st));
+      RCCL_CHECK(ncclGroupStart());
+      RCCL_CHECK(ncclSend(a.p, n_floats, ncclFloat, 0, comm, st));
+      RCCL_CHECK(ncclRecv(b.p, n_floats, ncclFloat, 0, comm, st));
+      RCCL_CHECK(ncclGroupEnd());
+      HIP_CHECK(hipStreamSynchronize(st));
+      HIP_CHECK(hipMemcpy(back.data(), b.p, size_t(n_floats) * 4, hipMemcpyDeviceToHost));
+    } catch (...) {
+      if (st) (void)hipStreamDestroy(st);
+      (void)ncclCommDestroy(comm);
+      throw;
+    }
+    (void)hipStreamDestroy(st);
+    RCCL_CHECK(ncclCommDestroy(comm));
+    if (std::memcmp(h.data(), back.data(), size_t(n_floats) * 4) != 0) throw RcclFailure("rccl selftest: the received slab differs from the sent one");
+  });
+}
+
 int yart_hip_multi_device_count(const YartMulti* multi) { return multi ? int(multi->scenes.size()) : 0; }
 
 int yart_hip_multi_render(YartMulti* multi, const YartCameraDesc* cam, const YartRenderParams* params, float* out_rgba,

@@ -153,8 +153,9 @@ typedef struct YartRenderParams {
                                        331 -> 364 ms); the reading code is compiled out of the default build (-DYART_SAMPLER_ROWS=1 brings it back; the
                                        flag is ignored otherwise) */
 #define YART_FLAG_WIDE_BVH 128u     /* lean traversal kernels walk a 4-wide re-layout of the reference's binary tree (same boxes,
-                                       same triangle tests; children nearest-first over four). Frames equal the binary walk's
-                                       except where two triangles are hit at exactly the same t */
+                                       same triangle tests; children nearest-first over four). Frames equal the binary walk's bit for bit: rays
+                                       that meet an alpha-tested triangle or two triangles at exactly the same t go to the general
+                                       kernels. Measured slower on the BASELINE scenes, hence opt-in */
 #define YART_FLAG_DIRECT_SAMPLER 8u /* evaluate every ZSobol index digit per draw (no per-render sampler tables) */
 #define YART_FLAG_NO_COMPACTION 32u  /* keep every bounce on the batch-sized path state (no copy of the survivors into a dense one) */
 #define YART_FLAG_GENERAL_TRACE 4u  /* general traversal kernels for every ray instead of lean kernels + retry */

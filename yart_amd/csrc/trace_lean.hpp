@@ -49,6 +49,11 @@ constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;   // leave the inner loo
 #define YART_LEAN_MASKED_LOADS 0
 #endif
 
+// lean shadow kernel without near / far ordering and with a fixed interval (trace_lean_bvh2.inc)
+#ifndef YART_SHADOW_ANYORDER
+#define YART_SHADOW_ANYORDER 0
+#endif
+
 struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general variant only (alpha tests)
 
 // Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)

@@ -294,6 +294,9 @@ int yart_hip_probe_hits(YartScene* scene, uint32_t n, const float* rays, float* 
 /* the 32 device counter words of the last render on this scene ([0] rays, [1..4] exact
  * traversal tallies in the instrumented build, [8..] kernel-phase statistics in debug builds) */
 int yart_hip_debug_counters(YartScene* scene, uint64_t* out32);
+/* measurement builds (-DYART_SHADE_REGIONS=1, tools/shade_regions.py) only: wave cycles [0..15], visits [16..31] and
+ * active lanes [32..47] per code region of the shade kernel since the last call; YART_E_INVALID in the product build */
+int yart_hip_debug_shade_regions(uint64_t* out48);
 int yart_hip_bvh_info(YartScene* scene, uint32_t mesh, uint32_t* n_nodes, uint32_t* n_tris);
 int yart_hip_bvh_copy(YartScene* scene, uint32_t mesh, uint32_t* nodes_out, uint32_t* indices_out);
 

@@ -181,7 +181,7 @@ EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error
            "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
            "yart_hip_scene_load_gltf", "yart_hip_gltf_to_yscn",
            "yart_hip_render", "yart_hip_render_waves", "yart_hip_render_tiles", "yart_hip_render_device", "yart_hip_probe_samples",
-           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_debug_counters",
+           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_debug_counters", "yart_hip_debug_shade_regions",
            "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host",
            "yart_hip_multi_create", "yart_hip_multi_load", "yart_hip_multi_destroy", "yart_hip_multi_device_count",
            "yart_hip_multi_render", "yart_hip_multi_rccl_selftest"]

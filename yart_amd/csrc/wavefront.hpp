@@ -56,6 +56,31 @@ struct WfTally {
 #define WF_TALLY_SHADE(t) ((void)0)
 #endif
 
+// Debug build -DYART_SHADE_REGIONS=1 (tools/shade_regions.py): where a wave of k_wf_shade spends its cycles. SR_MARK(k) at
+// the END of a code region charges the wave's cycles since its previous mark to region k (first active lane, accumulators
+// in LDS, so no registers are taken from the kernel) and counts the lanes that ran it. Empty otherwise.
+#if defined(YART_SHADE_REGIONS) && defined(__HIPCC__)
+constexpr int kShadeRegions = 16;
+__device__ unsigned long long g_shadeRegion[3 * kShadeRegions];   // [k] cycles, [16 + k] visits, [32 + k] lanes
+#endif
+#if defined(YART_SHADE_REGIONS) && defined(__HIP_DEVICE_COMPILE__)
+__shared__ unsigned long long srAcc[4][3 * kShadeRegions];
+__shared__ unsigned long long srLast[4];
+#define SR_MARK(k)                                                                       \
+  do {                                                                                   \
+    const unsigned long long _m = __ballot(true);                                        \
+    if (int(threadIdx.x & 63u) == __ffsll((long long) _m) - 1) {                         \
+      const unsigned long long _t = clock64();                                           \
+      unsigned long long* _a = srAcc[threadIdx.x >> 6];                                  \
+      _a[k] += _t - srLast[threadIdx.x >> 6]; _a[kShadeRegions + (k)] += 1ull;           \
+      _a[2 * kShadeRegions + (k)] += (unsigned long long) __popcll(_m);                  \
+      srLast[threadIdx.x >> 6] = clock64();                                              \
+    }                                                                                    \
+  } while (0)
+#else
+#define SR_MARK(k) ((void)0)
+#endif
+
 enum : uint32_t { WF_SPECULAR = 1u << 8, WF_REGULARIZED = 1u << 9, WF_MISS = 1u << 10, WF_DEPTH_MASK = 0xffu };
 
 // hit word of the path state: scene node (bits 0..19) | shade class = material index, or kWfClassMiss
@@ -218,6 +243,7 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
   const uint32_t depth = p.flags & WF_DEPTH_MASK;
   const bool specularBounce = (p.flags & WF_SPECULAR) != 0, regularized = (p.flags & WF_REGULARIZED) != 0;
   rays++;
+  SR_MARK(0);                                                   // path state loaded
   if (h0.x < 0.0f) {                                            // miss (mis-integrator.cpp:27-43)
     for (uint32_t k = 0; k < sc.nInfinite; k++) {
       const LightDev& l = sc.lights[sc.infiniteLights[k]];
@@ -230,25 +256,30 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
       }
     }
     p.L += p.att * rc.background;
+    SR_MARK(1);                                                 // miss: environment lookup + MIS
     return WF_TERMINATED;
   }
   HitRec hr;
   hr.t = h0.x; hr.u = h0.y; hr.v = h0.z; hr.tri = asU(h0.w); hr.node = nodeBack & ((1u << kWfNodeBits) - 1u);
   hr.backSide = (nodeBack >> 31) | (((nodeBack >> kWfNodeBits) & kWfClassMiss) << 1);
   Hit hit = finalizeHit(sc, hr, p.o, p.d);
+  SR_MARK(2);                                                   // finalizeHit
   WF_TALLY_SHADE(tally);
   const MaterialDev& mt = sc.materials[hit.material];
   f2 u = get2D(p.smp, rc.sampler, sobol);
   float uc = get1D(p.smp, rc.sampler);
   float uc2 = get1D(p.smp, rc.sampler);
+  SR_MARK(3);                                                   // sampler: one 2D + two 1D draws
   const f3 wo = -p.d;
   // one shading frame and one material fetch for sample / f / pdf (core/bsdf.cpp:5-58 builds the
   // same frame and fetches the same texels in each of the three calls)
   const Frame fr = shadingFrame(hit.n, hit.tg);
   const f3 woLocal = wtl(fr, wo);
   const MatEval me = matEvaluate(sc, mt, hit.uv);
+  SR_MARK(4);                                                   // shading frame + material / texture fetch
   BsdfSample res = bsdfSampleImplE(sc, mt, me, woLocal, hit.uv, u, uc, uc2, regularized);
   res.wi = ltw(fr, res.wi);
+  SR_MARK(5);                                                   // BSDF sample
   if (res.scatter & SC_EMITTED) {
     if (depth == 0 || specularBounce) p.L += p.att * res.Le;
     else if (hit.lightIdx != -1) {
@@ -276,6 +307,7 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
     if (q.accRoughness > 0.5f) fl |= WF_REGULARIZED;
     p.flags = fl;
   }
+  SR_MARK(6);                                                   // emission MIS, throughput, new ray stored
 #if defined(YART_EXP_SKIP_NEE)      // timing experiment only (wrong frames): the shade kernel without its NEE block
   const bool nee = false;
 #else
@@ -287,12 +319,15 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
     if (sc.nLights != 0) {                                      // Ld set-up (:111-124)
       float ucl = get1D(p.smp, rc.sampler);
       f2 ul = get2D(p.smp, rc.sampler, sobol);
+      SR_MARK(7);                                               // sampler: NEE draws (1D + 2D)
       float pl;
       uint32_t li = lightSamplerSample(sc, ucl, pl);
       const LightDev& l = sc.lights[li];
       LightSample ls = lightSample(sc, l, hit.p, ul);
       const f3 wiLocal = wtl(fr, ls.wi);
+      SR_MARK(8);                                               // light choice + light sample (environment importance sampling)
       f3 f = bsdfFImplE(sc, mt, me, woLocal, wiLocal);
+      SR_MARK(9);                                               // BSDF f for the light direction
       if (length2(f) != 0.0f) {
         // evaluated eagerly (pure); the reference evaluates them after the occlusion test
         float pdfBSDF = bsdfPdfImplE(sc, mt, me, woLocal, wiLocal);
@@ -303,6 +338,7 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
         wfSt(s.sh1 + i, mk4(p.att.x, p.att.y, p.att.z, pdfBSDF + pdfLight));
         wfSt(s.sh2 + i, mk4(Lif.x, Lif.y, Lif.z, absDot(ls.wi, hit.n)));
         shadow = true;
+        SR_MARK(10);                                            // BSDF pdf, shadow-ray set-up stored
       }
     }
     // Ld returned {} (no lights / f == 0): the reference still executes L += attenuation * 0,

@@ -1117,6 +1117,24 @@ int yart_hip_debug_counters(YartScene* scene, uint64_t* out32) {
   });
 }
 
+/* debug build -DYART_SHADE_REGIONS=1 only (tools/shade_regions.py): cycles / visits / lanes per code region of k_wf_shade,
+ * summed over the renders since the last call (16 regions x 3); -1 otherwise */
+int yart_hip_debug_shade_regions(uint64_t* out48) {
+#if defined(YART_SHADE_REGIONS)
+  return guarded([&] {
+    require(out48 != nullptr, "null pointer");
+    unsigned long long v[3 * 16];
+    HIP_CHECK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_shadeRegion), sizeof(v)));
+    for (int i = 0; i < 48; i++) out48[i] = v[i];
+    const unsigned long long zero[3 * 16] = {0};
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_shadeRegion), zero, sizeof(zero)));
+  });
+#else
+  (void)out48;
+  return YART_E_INVALID;
+#endif
+}
+
 int yart_hip_bvh_info(YartScene* scene, uint32_t mesh, uint32_t* n_nodes, uint32_t* n_tris) {
   return guarded([&] {
     require(scene && n_nodes && n_tris, "null pointer");

@@ -74,19 +74,27 @@ YART_HD LightSample envSample(const SceneDev& sc, const LightDev& l, f2 u) {   /
   uint32_t ov, ou;
   // marginal over v with u.y, then conditional row with u.x (sampling.cpp:36-43)
   const uint32_t* gm = e.guideKh ? sc.envGuide + e.guideOffset : nullptr;
+#if defined(YART_EXP_ENV_NOCDF)      // timing experiment only (wrong frames): no CDF searches, a uniform sample of the map
+  float d1 = u.y, d0 = u.x; pdf1 = 1.0f; pdf0 = 1.0f; ov = 0; ou = 0; (void)gm;
+#else
   float d1 = pc1dSample(sc.envData + e.rowIntOffset, sc.envData + e.margCdfOffset, e.h, e.margIntegral,
                         0.0f, 1.0f, u.y, pdf1, ov, gm, e.guideKh);
   float rowInt = sc.envData[e.rowIntOffset + ov];
   const uint32_t* gr = e.guideKw ? sc.envGuide + e.guideOffset + (e.guideKh + 1u) + size_t(ov) * (e.guideKw + 1u) : nullptr;
   float d0 = pc1dSample(sc.envData + e.funcOffset + ov * e.w, sc.envData + e.cdfOffset + ov * (e.w + 1),
                         e.w, rowInt, 0.0f, 1.0f, u.x, pdf0, ou, gr, e.guideKw);
+#endif
   float pdf = pdf0 * pdf1;
   if (pdf == 0.0f) return emptyLightSample();
   f2 uv = mk2(d0, d1);
   f3 wi = mulVector(l.xf.fwd, invOctahedralUV(uv));
   pdf /= e.surfaceArea;
   LightSample s;
+#if defined(YART_EXP_ENV_NOTEX)       // timing experiment only (wrong frames): no radiance lookup
+  s.Li = mk3(1.0f);
+#else
   s.Li = envLe(sc, l, uv);
+#endif
   s.wi = wi;
   s.p = (wi * 2.0f) * l.radius;
   s.n = -wi;

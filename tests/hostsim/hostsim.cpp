@@ -133,7 +133,7 @@ static int doKat(Ctx& c, const params::Params& p, const std::string& outPath) {
       io.push_back(hit);
       if (!hit) { io.push_back(-1); io.push_back(-1); io.push_back(0); for (int k = 0; k < 12; k++) fo.push_back(0); continue; }
       Hit h = finalizeHit(c.sc, hr, o, d);
-      io.push_back(hr.tri); io.push_back(h.lightIdx); io.push_back(h.backSide);
+      io.push_back(localTri(c.sc, hr)); io.push_back(h.lightIdx); io.push_back(h.backSide);
       fo.push_back(h.t); fo.push_back(h.uv.x); fo.push_back(h.uv.y);
       fo.push_back(h.p.x); fo.push_back(h.p.y); fo.push_back(h.p.z);
       fo.push_back(h.n.x); fo.push_back(h.n.y); fo.push_back(h.n.z);

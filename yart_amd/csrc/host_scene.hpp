@@ -209,7 +209,7 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
       const float* p2 = m.positions + size_t(m.faces[4 * t + 2]) * 3;
       LeafTri lt{};
       for (int c = 0; c < 3; c++) { lt.p0[c] = p0[c]; lt.e1[c] = p1[c] - p0[c]; lt.e2[c] = p2[c] - p0[c]; }
-      lt.triIdx = t;
+      lt.triIdx = md.triOffset + t;       // index of the ShadeTri record (scene-wide): the hit needs no mesh look-up to find it
       lt.material = m.faces[4 * t + 3];
       lt.matFlags = im.materials[lt.material].flags & (MAT_HAS_ALPHA | MAT_TRANSPARENT);
       im.leafTris.push_back(lt);

@@ -63,7 +63,7 @@ struct BvhNode {           // core/bvh.hpp:21-33 (32 bytes)
 };
 
 struct LeafTri {           // 48 bytes, leaf order
-  float p0[3]; uint32_t triIdx;
+  float p0[3]; uint32_t triIdx;      // MeshDev::triOffset + triangle: index into SceneDev::shadeTris
   float e1[3]; uint32_t matFlags;   // MAT_HAS_ALPHA | MAT_TRANSPARENT of the triangle's material; first record of a leaf: | span << 8
   float e2[3]; uint32_t material;
 };

@@ -50,7 +50,6 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
   const BvhNode* nodes = sc.bvhNodes;
   const LeafTri* leaves = sc.leafTris;
   bool meshHasAlpha = false;
-  uint32_t meshIdx = 0;
   // MODE & TRAV_WIDE (trace_wide_bvh.inc): cursor into the mesh's 4-wide records, their base, the interval end on entering the mesh
   uint32_t wideCur = 0, wideBase = 0;
   float tEntry = 0.0f;
@@ -173,7 +172,7 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
               if (!(NEE && kFast && didHit && !mesh.hasAlpha)) { // pruning of occluded shadow rays (traverse.hpp)
                 nodes = sc.bvhNodes + mesh.nodeOffset;
                 leaves = sc.leafTris + mesh.leafOffset;
-                meshHasAlpha = mesh.hasAlpha != 0; meshIdx = uint32_t(nd.mesh);
+                meshHasAlpha = mesh.hasAlpha != 0;
                 const BvhNode root = nodes[0];
                 YART_COUNT(nBox, 1);
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry

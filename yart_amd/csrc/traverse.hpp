@@ -167,9 +167,9 @@ struct AlphaCtx {            // state the stochastic alpha test draws from
 };
 
 // uv / normal interpolation of ray-integrator.cpp:198-213
-YART_HD void interpUVN(const SceneDev& sc, const MeshDev& mesh, uint32_t tri, float u, float v, f2& uv,
-                       f3& n) {
-  const ShadeTri& st = sc.shadeTris[mesh.triOffset + tri];
+// (tri: scene-wide index of the triangle's ShadeTri record, as the leaf records and HitRec::tri carry it)
+YART_HD void interpUVN(const SceneDev& sc, uint32_t tri, float u, float v, f2& uv, f3& n) {
+  const ShadeTri& st = sc.shadeTris[tri];
   const float w = 1.0f - u - v;
   const f2 t0 = mk2(st.uv[0][0], st.uv[0][1]), t1 = mk2(st.uv[1][0], st.uv[1][1]), t2 = mk2(st.uv[2][0], st.uv[2][1]);
   uv = (w * t0 + u * t1) + v * t2;
@@ -283,7 +283,7 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
         if (!(MODE & TRAV_FAST) && (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT))) {
           // slow path: alpha cut-outs and NEE-transparent surfaces
           f2 uv; f3 n;
-          interpUVN(sc, mesh, tr.triIdx, u, v, uv, n);
+          interpUVN(sc, tr.triIdx, u, v, uv, n);
           const MaterialDev& mt = sc.materials[tr.material];
           if (tr.matFlags & MAT_HAS_ALPHA) {
             float alpha = matAlpha(sc, mt, uv);
@@ -400,18 +400,18 @@ YART_HD bool traverseScene(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& h
 
 // testTriangle's hit fields + testMesh (ray-integrator.cpp:56-82) + the object->world
 // chain of testNode (:50-52) for the final hit.
+// the triangle's index within its mesh (what the reference's Hit reports), from the scene-wide one of the hit record
+YART_HD uint32_t localTri(const SceneDev& sc, const HitRec& r) { return r.tri - sc.meshes[sc.nodes[r.node].mesh].triOffset; }
 YART_HD Hit finalizeHit(const SceneDev& sc, const HitRec& r, f3 o, f3 d) {
-  const NodeDev& nd = sc.nodes[r.node];
-  const MeshDev& mesh = sc.meshes[nd.mesh];
   f3 oo, od;
   objectRay(sc, r.node, o, d, oo, od);
   Hit h;
   h.t = r.t;
   f3 n;
-  interpUVN(sc, mesh, r.tri, r.u, r.v, h.uv, n);
+  interpUVN(sc, r.tri, r.u, r.v, h.uv, n);
   h.p = oo + (r.t * od);                                   // ray(t), ray.hpp:27-29
   h.backSide = (r.backSide & 1u) != 0;
-  const ShadeTri& st = sc.shadeTris[mesh.triOffset + r.tri];
+  const ShadeTri& st = sc.shadeTris[r.tri];        // (HitRec::tri is scene-wide: no node -> mesh -> offset chain in front of this gather)
   // the material index travels with the hit (every traversal variant packs it above the back-side bit): the material
   // record is fetched without waiting for the triangle's shade record
   h.material = r.backSide >> 1;

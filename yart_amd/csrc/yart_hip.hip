@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(kBlock) k_probe_hits(ProbeHitArgs a) {
     q[1] = h.t; q[2] = hr.u; q[3] = hr.v;
     q[4] = h.p.x; q[5] = h.p.y; q[6] = h.p.z; q[7] = h.n.x; q[8] = h.n.y; q[9] = h.n.z;
     q[10] = h.tg.x; q[11] = h.tg.y; q[12] = h.tg.z;
-    q[13] = float(hr.tri); q[14] = float(h.lightIdx); q[15] = h.backSide ? 1.0f : 0.0f;
+    q[13] = float(localTri(a.sc, hr)); q[14] = float(h.lightIdx); q[15] = h.backSide ? 1.0f : 0.0f;
   }
 }
 

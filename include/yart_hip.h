@@ -298,6 +298,16 @@ int yart_hip_debug_counters(YartScene* scene, uint64_t* out32);
  * active lanes [32..47] per code region of the shade kernel since the last call; YART_E_INVALID in the product build */
 int yart_hip_debug_shade_regions(uint64_t* out48);
 int yart_hip_bvh_info(YartScene* scene, uint32_t mesh, uint32_t* n_nodes, uint32_t* n_tris);
+/* The reference's binned-SAH build (core/bvh.hpp:41-184, 273-347) of one mesh, outside a scene: on the device
+ * (csrc/bvh_build_device.inc: level by level, one workgroup per node, the sequential partition in closed form) and on
+ * the host (csrc/bvh_build_host = csrc/bvh_build.hpp, `threads` workers, 0 = all). Both write the reference's node array
+ * (8 words per node: bounds, left|first, span; room for 2 * n_faces nodes) and index permutation, byte for byte the
+ * same. faces: n_faces x face_stride words, the first three of each the vertex indices. The device build refuses input
+ * with NaN coordinates or a tree deeper than 192 levels (YART_E_INVALID): build those on the host. */
+int yart_hip_bvh_build_device(int device, const float* positions, uint32_t n_verts, const uint32_t* faces, uint32_t face_stride,
+                              uint32_t n_faces, uint32_t* nodes_out, uint32_t* indices_out, uint32_t* n_nodes, double* ms_device);
+int yart_hip_bvh_build_host(const float* positions, uint32_t n_verts, const uint32_t* faces, uint32_t face_stride, uint32_t n_faces,
+                            uint32_t threads, uint32_t* nodes_out, uint32_t* indices_out, uint32_t* n_nodes, double* ms_host);
 int yart_hip_bvh_copy(YartScene* scene, uint32_t mesh, uint32_t* nodes_out, uint32_t* indices_out);
 
 /* The step after the path: AgX tonemap of the RGBA32F frame as

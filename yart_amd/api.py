@@ -181,7 +181,7 @@ EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error
            "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
            "yart_hip_scene_load_gltf", "yart_hip_gltf_to_yscn",
            "yart_hip_render", "yart_hip_render_waves", "yart_hip_render_tiles", "yart_hip_render_device", "yart_hip_probe_samples",
-           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_debug_counters", "yart_hip_debug_shade_regions",
+           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_bvh_build_device", "yart_hip_bvh_build_host", "yart_hip_debug_counters", "yart_hip_debug_shade_regions",
            "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host",
            "yart_hip_multi_create", "yart_hip_multi_load", "yart_hip_multi_destroy", "yart_hip_multi_device_count",
            "yart_hip_multi_render", "yart_hip_multi_rccl_selftest"]
@@ -236,6 +236,29 @@ def lib(instrumented: bool = False):
 def _check(code, L=None):
     if code != YART_OK:
         raise YartError(code, (L or lib()).yart_hip_last_error().decode())
+
+
+def bvh_build(positions, faces, device=None, threads=0):
+    """The reference's binned-SAH BVH of one mesh, built outside a scene: on HIP device ``device`` (csrc/bvh_build_device.inc)
+    or, with ``device=None``, on the host (csrc/bvh_build.hpp, ``threads`` workers, 0 = all). Returns (nodes (n, 8) u32 —
+    bounds as float bits, left|first, span —, indices (n_faces,) u32, milliseconds); both builds give the same bytes."""
+    L = lib()
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    f = np.ascontiguousarray(faces, np.uint32)
+    f = f.reshape(len(f), -1)
+    nodes = np.zeros((2 * len(f), 8), np.uint32)
+    idx = np.zeros(len(f), np.uint32)
+    n, ms = C.c_uint32(0), C.c_double(0)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    if device is None:
+        L.yart_hip_bvh_build_host.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        _check(L.yart_hip_bvh_build_host(vp(pos), len(pos), vp(f), f.shape[1], len(f), threads, vp(nodes), vp(idx), C.byref(n), C.byref(ms)), L)
+    else:
+        L.yart_hip_bvh_build_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        _check(L.yart_hip_bvh_build_device(int(device), vp(pos), len(pos), vp(f), f.shape[1], len(f), vp(nodes), vp(idx), C.byref(n), C.byref(ms)), L)
+    return nodes[:n.value].copy(), idx, ms.value
 
 
 def _f(arr, n):

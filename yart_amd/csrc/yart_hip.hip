@@ -786,6 +786,7 @@ std::unique_ptr<LoadedScene> importGltf(const char* path, const YartImportOption
 }  // namespace
 
 #include "multi_device.inc"
+#include "bvh_build_device.inc"
 
 extern "C" {
 
@@ -1155,6 +1156,41 @@ int yart_hip_bvh_copy(YartScene* scene, uint32_t mesh, uint32_t* nodes_out, uint
                         hipMemcpyDeviceToHost));
     for (uint32_t n = 0; n < m.nNodes; n++) nodes_out[size_t(n) * 8 + 6] &= kLinkIndexMask;   // the reference's index only
     std::memcpy(indices_out, scene->host.bvhIndices[mesh].data(), size_t(m.nTris) * 4);
+  });
+}
+
+int yart_hip_bvh_build_device(int device, const float* positions, uint32_t n_verts, const uint32_t* faces, uint32_t face_stride,
+                              uint32_t n_faces, uint32_t* nodes_out, uint32_t* indices_out, uint32_t* n_nodes, double* ms_device) {
+  return guarded([&] {
+    require(positions && faces && nodes_out && indices_out && n_nodes, "null pointer");
+    require(n_faces >= 1 && n_faces <= kLinkIndexMask && face_stride >= 3, "bvh build: bad triangle count or stride");
+    for (size_t k = 0; k < size_t(n_faces) * face_stride; k += face_stride)
+      for (int c = 0; c < 3; c++) require(faces[k + c] < n_verts, "bvh build: vertex index out of range");
+    std::vector<BvhNode> nodes;
+    std::vector<uint32_t> indices;
+    require(devbvh::build(device, positions, n_verts, faces, face_stride, n_faces, nodes, indices, ms_device),
+            "bvh build: refused on the device (NaN coordinate or tree deeper than 192 levels): build on the host");
+    *n_nodes = uint32_t(nodes.size());
+    std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(BvhNode));
+    std::memcpy(indices_out, indices.data(), indices.size() * 4);
+  });
+}
+
+int yart_hip_bvh_build_host(const float* positions, uint32_t n_verts, const uint32_t* faces, uint32_t face_stride, uint32_t n_faces,
+                            uint32_t threads, uint32_t* nodes_out, uint32_t* indices_out, uint32_t* n_nodes, double* ms_host) {
+  return guarded([&] {
+    require(positions && faces && nodes_out && indices_out && n_nodes, "null pointer");
+    require(n_faces >= 1 && n_faces <= kLinkIndexMask && face_stride >= 3, "bvh build: bad triangle count or stride");
+    for (size_t k = 0; k < size_t(n_faces) * face_stride; k += face_stride)
+      for (int c = 0; c < 3; c++) require(faces[k + c] < n_verts, "bvh build: vertex index out of range");
+    const auto t0 = std::chrono::steady_clock::now();
+    SahBvhBuilder b;
+    b.setThreads(threads);
+    b.build(positions, faces, face_stride, n_faces);
+    if (ms_host) *ms_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *n_nodes = uint32_t(b.nodes.size());
+    std::memcpy(nodes_out, b.nodes.data(), b.nodes.size() * sizeof(BvhNode));
+    std::memcpy(indices_out, b.indices.data(), b.indices.size() * 4);
   });
 }
 

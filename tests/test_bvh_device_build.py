@@ -73,3 +73,19 @@ def test_device_build_refuses_nan():
     pos[17, 1] = np.nan
     with pytest.raises(api.YartError):
         api.bvh_build(pos, faces, device=0)
+
+
+@pytest.mark.gpu
+def test_scene_with_device_built_bvhs_renders_the_same_frame():
+    """YART_SCENE_DEVICE_BVH: every mesh's BVH from the device build — the node arrays the kernels traverse and the frame
+    are those of the host-built scene, bit for bit (instanced scene: shared meshes, transformed nodes, alpha card)."""
+    scene, p = scenes.material_test(96, 64, 8, 5)
+    a = api.DeviceScene(scene, device=0)
+    b = api.DeviceScene(scene, device=0, device_bvh=True)
+    for m in range(len(scene.meshes)):
+        na, ia = a.bvh(m)
+        nb, ib = b.bvh(m)
+        assert np.array_equal(na, nb) and np.array_equal(ia, ib)
+    fa, _ = a.render(p)
+    fb, _ = b.render(p)
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))

@@ -181,7 +181,7 @@ EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error
            "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
            "yart_hip_scene_load_gltf", "yart_hip_gltf_to_yscn",
            "yart_hip_render", "yart_hip_render_waves", "yart_hip_render_tiles", "yart_hip_render_device", "yart_hip_probe_samples",
-           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_bvh_build_device", "yart_hip_bvh_build_host", "yart_hip_debug_counters", "yart_hip_debug_shade_regions",
+           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_scene_create_flags", "yart_hip_bvh_build_device", "yart_hip_bvh_build_host", "yart_hip_debug_counters", "yart_hip_debug_shade_regions",
            "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host",
            "yart_hip_multi_create", "yart_hip_multi_load", "yart_hip_multi_destroy", "yart_hip_multi_device_count",
            "yart_hip_multi_render", "yart_hip_multi_rccl_selftest"]
@@ -295,7 +295,7 @@ class DeviceScene:
     """Owns a ``YartScene*`` (device-resident flattened scene + BVHs)."""
 
     def __init__(self, scene, device: int = -1, instrumented: bool = False, env_hdr=None, env_radius=100.0,
-                 uniform_env=None):
+                 uniform_env=None, device_bvh: bool = False):
         """scene: a :class:`yscn.Scene`, the path of a ``.yscn`` container, or the path of a ``.glb`` / ``.gltf``
         asset (then env_hdr / env_radius / uniform_env give the environment light, as main.cpp:80-86)."""
         self._h = C.c_void_p()
@@ -309,7 +309,11 @@ class DeviceScene:
             _check(self._L.yart_hip_scene_load(os.fspath(scene).encode(), device, C.byref(self._h)), self._L)
         else:
             desc = self._describe(scene)
-            _check(self._L.yart_hip_scene_create(C.byref(desc), device, C.byref(self._h)), self._L)
+            if device_bvh:      # YART_SCENE_DEVICE_BVH: the meshes' BVHs built on the device (same bytes as the host build)
+                self._L.yart_hip_scene_create_flags.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+                _check(self._L.yart_hip_scene_create_flags(C.byref(desc), device, 1, C.byref(self._h)), self._L)
+            else:
+                _check(self._L.yart_hip_scene_create(C.byref(desc), device, C.byref(self._h)), self._L)
         self._keep = []     # the library copies everything it needs
 
     def _describe(self, s: yscn.Scene) -> SceneDesc:

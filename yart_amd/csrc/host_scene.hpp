@@ -108,7 +108,11 @@ inline float triangleAreaHost(f3 p0, f3 p1, f3 p2) {       // primitives.hpp:24-
   return length(cross(p1 - p0, p2 - p0)) * 0.5f;
 }
 
-inline HostImage buildHostImage(const YartSceneDesc& d) {
+// optional builder for the BVH of one mesh (the device build of bvh_build_device.inc): fills nodes / indices and returns
+// true, or returns false to leave the mesh to the host builder — the two give the same bytes
+typedef bool (*MeshBvhFn)(void* ctx, const float* positions, uint32_t nVerts, const uint32_t* faces, uint32_t stride, uint32_t nFaces,
+                          std::vector<BvhNode>& nodes, std::vector<uint32_t>& indices);
+inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullptr, void* bvhCtx = nullptr) {
   require(d.n_nodes >= 1 && d.nodes, "scene needs a root node");
   require(d.n_materials == 0 || d.materials, "materials pointer is null");
   require(d.n_meshes == 0 || d.meshes, "meshes pointer is null");
@@ -194,12 +198,15 @@ inline HostImage buildHostImage(const YartSceneDesc& d) {
     md.vertOffset = uint32_t(im.vPos.size());
     md.nTris = m.n_faces; md.nVerts = m.n_vertices;
 
-    SahBvhBuilder b;
-    {   // YART_BVH_THREADS: worker threads of the build (default: all hardware threads, at most 32; 1 = serial)
+    struct { std::vector<BvhNode> nodes; std::vector<uint32_t> indices; } b;
+    if (!(bvhFn && bvhFn(bvhCtx, m.positions, m.n_vertices, m.faces, 4, m.n_faces, b.nodes, b.indices))) {
+      SahBvhBuilder hb;
+      // YART_BVH_THREADS: worker threads of the build (default: all hardware threads, at most 32; 1 = serial)
       const char* e = std::getenv("YART_BVH_THREADS");
-      b.setThreads(e ? unsigned(std::atoi(e)) : 0u);
+      hb.setThreads(e ? unsigned(std::atoi(e)) : 0u);
+      hb.build(m.positions, m.faces, 4, m.n_faces);
+      b.nodes = std::move(hb.nodes); b.indices = std::move(hb.indices);
     }
-    b.build(m.positions, m.faces, 4, m.n_faces);
     md.nNodes = uint32_t(b.nodes.size());
     im.bvhNodes.insert(im.bvhNodes.end(), b.nodes.begin(), b.nodes.end());
     for (uint32_t k = 0; k < m.n_faces; k++) {

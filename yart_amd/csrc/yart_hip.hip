@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(kBlock) k_probe_hits(ProbeHitArgs a) {
 }
 
 #include "wavefront_kernels.inc"
+#include "bvh_build_device.inc"
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -335,13 +336,20 @@ int resolveDevice(int device) {
   return device < count ? device : -1;
 }
 
-YartScene* createScene(const YartSceneDesc& desc, int device) {
+// YART_SCENE_DEVICE_BVH: the meshes' BVHs are built on the device (same bytes; a mesh the device build refuses — NaN
+// coordinates — is built on the host)
+static bool deviceMeshBvh(void* ctx, const float* positions, uint32_t nVerts, const uint32_t* faces, uint32_t stride, uint32_t nFaces,
+                          std::vector<BvhNode>& nodes, std::vector<uint32_t>& indices) {
+  return devbvh::build(*static_cast<int*>(ctx), positions, nVerts, faces, stride, nFaces, nodes, indices, nullptr);
+}
+YartScene* createScene(const YartSceneDesc& desc, int device, uint32_t sceneFlags = 0) {
   int dev = resolveDevice(device);
   if (dev < 0) throw HipError("no usable HIP device (libyart_hip has no CPU fallback)");
   HIP_CHECK(hipSetDevice(dev));
   auto s = std::make_unique<YartScene>();
   s->device = dev;
-  s->host = buildHostImage(desc);
+  if (sceneFlags & YART_SCENE_DEVICE_BVH) s->host = buildHostImage(desc, deviceMeshBvh, &dev);
+  else s->host = buildHostImage(desc);
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, dev));
   s->numCUs = prop.multiProcessorCount;
@@ -786,7 +794,6 @@ std::unique_ptr<LoadedScene> importGltf(const char* path, const YartImportOption
 }  // namespace
 
 #include "multi_device.inc"
-#include "bvh_build_device.inc"
 
 extern "C" {
 
@@ -804,6 +811,13 @@ int yart_hip_scene_create(const YartSceneDesc* desc, int device, YartScene** out
   return guarded([&] {
     require(desc && out, "desc / out pointer is null");
     *out = createScene(*desc, device);
+  });
+}
+
+int yart_hip_scene_create_flags(const YartSceneDesc* desc, int device, uint32_t scene_flags, YartScene** out) {
+  return guarded([&] {
+    require(desc && out, "desc / out pointer is null");
+    *out = createScene(*desc, device, scene_flags);
   });
 }
 

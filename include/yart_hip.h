@@ -195,12 +195,13 @@ typedef struct YartStats {
 
 typedef struct YartScene YartScene;
 
-/* Build the device scene (BVH build per mesh, flattening, upload). device < 0: current. */
+/* Build the device scene (BVH build per mesh — on the device, see yart_hip_scene_create_flags —, flattening, upload). device < 0: current. */
 int yart_hip_scene_create(const YartSceneDesc* desc, int device, YartScene** out);
-/* ... with options. YART_SCENE_DEVICE_BVH: the BVH of every mesh is built on the device (yart_hip_bvh_build_device: the
- * same node array and index permutation as the host build, so the same frames); a mesh the device build refuses is
- * built on the host. */
+/* ... with options. The BVH of every mesh is built on the device (yart_hip_bvh_build_device: the same node array and index
+ * permutation as the host build, so the same frames; a mesh the device build refuses is built on the host) unless
+ * YART_SCENE_HOST_BVH — or the environment variable YART_HOST_BVH — asks for the host builder. YART_SCENE_DEVICE_BVH names the default. */
 #define YART_SCENE_DEVICE_BVH 1u
+#define YART_SCENE_HOST_BVH 2u
 int yart_hip_scene_create_flags(const YartSceneDesc* desc, int device, uint32_t scene_flags, YartScene** out);
 /* Same, from a .yscn container (yart_amd/yscn.py). */
 int yart_hip_scene_load(const char* path, int device, YartScene** out);

@@ -77,11 +77,11 @@ def test_device_build_refuses_nan():
 
 @pytest.mark.gpu
 def test_scene_with_device_built_bvhs_renders_the_same_frame():
-    """YART_SCENE_DEVICE_BVH: every mesh's BVH from the device build — the node arrays the kernels traverse and the frame
-    are those of the host-built scene, bit for bit (instanced scene: shared meshes, transformed nodes, alpha card)."""
+    """Scenes get their BVHs from the device build by default; with YART_SCENE_HOST_BVH from the host builder. The node arrays
+    the kernels traverse and the frame are the same, bit for bit (instanced scene: shared meshes, transformed nodes, alpha card)."""
     scene, p = scenes.material_test(96, 64, 8, 5)
-    a = api.DeviceScene(scene, device=0)
-    b = api.DeviceScene(scene, device=0, device_bvh=True)
+    a = api.DeviceScene(scene, device=0, host_bvh=True)
+    b = api.DeviceScene(scene, device=0)
     for m in range(len(scene.meshes)):
         na, ia = a.bvh(m)
         nb, ib = b.bvh(m)

@@ -295,7 +295,7 @@ class DeviceScene:
     """Owns a ``YartScene*`` (device-resident flattened scene + BVHs)."""
 
     def __init__(self, scene, device: int = -1, instrumented: bool = False, env_hdr=None, env_radius=100.0,
-                 uniform_env=None, device_bvh: bool = False):
+                 uniform_env=None, host_bvh: bool = False):
         """scene: a :class:`yscn.Scene`, the path of a ``.yscn`` container, or the path of a ``.glb`` / ``.gltf``
         asset (then env_hdr / env_radius / uniform_env give the environment light, as main.cpp:80-86)."""
         self._h = C.c_void_p()
@@ -309,9 +309,9 @@ class DeviceScene:
             _check(self._L.yart_hip_scene_load(os.fspath(scene).encode(), device, C.byref(self._h)), self._L)
         else:
             desc = self._describe(scene)
-            if device_bvh:      # YART_SCENE_DEVICE_BVH: the meshes' BVHs built on the device (same bytes as the host build)
+            if host_bvh:      # YART_SCENE_HOST_BVH: the meshes' BVHs from the host builder instead of the device build (same bytes)
                 self._L.yart_hip_scene_create_flags.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
-                _check(self._L.yart_hip_scene_create_flags(C.byref(desc), device, 1, C.byref(self._h)), self._L)
+                _check(self._L.yart_hip_scene_create_flags(C.byref(desc), device, 2, C.byref(self._h)), self._L)
             else:
                 _check(self._L.yart_hip_scene_create(C.byref(desc), device, C.byref(self._h)), self._L)
         self._keep = []     # the library copies everything it needs

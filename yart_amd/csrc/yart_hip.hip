@@ -336,8 +336,7 @@ int resolveDevice(int device) {
   return device < count ? device : -1;
 }
 
-// YART_SCENE_DEVICE_BVH: the meshes' BVHs are built on the device (same bytes; a mesh the device build refuses — NaN
-// coordinates — is built on the host)
+// the device build of one mesh's BVH (same bytes as the host build; a mesh it refuses — NaN coordinates — is left to the host)
 static bool deviceMeshBvh(void* ctx, const float* positions, uint32_t nVerts, const uint32_t* faces, uint32_t stride, uint32_t nFaces,
                           std::vector<BvhNode>& nodes, std::vector<uint32_t>& indices) {
   return devbvh::build(*static_cast<int*>(ctx), positions, nVerts, faces, stride, nFaces, nodes, indices, nullptr);
@@ -348,8 +347,10 @@ YartScene* createScene(const YartSceneDesc& desc, int device, uint32_t sceneFlag
   HIP_CHECK(hipSetDevice(dev));
   auto s = std::make_unique<YartScene>();
   s->device = dev;
-  if (sceneFlags & YART_SCENE_DEVICE_BVH) s->host = buildHostImage(desc, deviceMeshBvh, &dev);
-  else s->host = buildHostImage(desc);
+  // the meshes' BVHs are built on the device unless the caller (YART_SCENE_HOST_BVH) or the environment (YART_HOST_BVH) asks
+  // for the host builder; the two give the same bytes, and every GPU test that compares a frame with the reference's checks it
+  if ((sceneFlags & YART_SCENE_HOST_BVH) || std::getenv("YART_HOST_BVH")) s->host = buildHostImage(desc);
+  else s->host = buildHostImage(desc, deviceMeshBvh, &dev);
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, dev));
   s->numCUs = prop.multiProcessorCount;

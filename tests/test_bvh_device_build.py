@@ -89,3 +89,23 @@ def test_scene_with_device_built_bvhs_renders_the_same_frame():
     fa, _ = a.render(p)
     fb, _ = b.render(p)
     assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_device_build_fuzz():
+    """80 random meshes — soups, duplicated triangles, triangles snapped to a coarse lattice (many equal centroids and
+    bounds, exact zeros), slivers along one axis — of 1 to 6000 triangles: every one byte-identical to the host build."""
+    rng = np.random.RandomState(20240607)
+    for case in range(80):
+        n = int(rng.choice([1, 2, 3, 7, 21, 22, 64, 65, 257, 300, 1000, 2049, 6000]))
+        kind = case % 4
+        p, f = _soup(n, 1000 + case, extent=float(rng.choice([0.5, 4.0, 50.0])), size=float(rng.choice([0.01, 0.3, 2.0])))
+        if kind == 1:                                   # snapped to a lattice
+            p = (np.round(p * 2.0) / 2.0).astype(np.float32)
+        elif kind == 2:                                 # duplicates: each triangle repeated 1..5 times
+            f = np.repeat(f, rng.randint(1, 6, size=len(f)), axis=0)[:max(n, 1)]
+        elif kind == 3:                                 # slivers along x
+            p[:, 1:] *= 1e-3
+        hn, hi, _ = api.bvh_build(p, f, device=None, threads=1)
+        dn, di, _ = api.bvh_build(p, f, device=0)
+        assert np.array_equal(di, hi) and np.array_equal(dn, hn), f"case {case}: kind {kind}, {len(f)} triangles"

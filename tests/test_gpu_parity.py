@@ -35,7 +35,10 @@ def api(built):
 
 PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+shade_sort": 2, "wavefront+general_trace": 4,
                   "wavefront+direct_sampler": 8, "wavefront+no_refill": 16, "wavefront+no_compaction": 32,
-                  "wavefront+no_shade_sort": 64, "wavefront+wide_bvh": 128}
+                  "wavefront+no_shade_sort": 64, "wavefront+wide_bvh": 128,
+                  # scenes of 64 nodes and more: per-lane walk of the node list instead of chunked candidate masks (the form
+                  # scenes of 512 nodes and more get by default; a no-op for smaller scene graphs)
+                  "wavefront+node_walk": 65536, "wavefront+node_walk+wide_bvh": 65536 | 128}
 
 
 @pytest.mark.parametrize("pipeline", list(PIPELINE_FLAGS))
@@ -241,7 +244,7 @@ def test_edge_cases_vs_oracle_live(api, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(ORACLE_BIN), reason="oracle restatement not built")
-@pytest.mark.parametrize("n_instances", [20, 58, 70, 250])
+@pytest.mark.parametrize("n_instances", [20, 58, 70, 250, 600])
 def test_instanced_scene_vs_oracle_live(api, tmp_path, n_instances):
     """Scene-graph walk: nested transformed group / instance nodes. 58 instances = exactly 64
     nodes (one chunk of the per-ray node candidate mask of trace_lean.hpp), 70 = 76 nodes (two

@@ -349,11 +349,13 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
       l[c] = finite ? float(mn[c] - pad) : -kInf;               // float() rounds to nearest: the pad dwarfs it
       h[c] = finite ? float(mx[c] + pad) : kInf;
     }
-    // .w of the pair: bits of the node's pre-order subtree [i, skip) as a 64-bit mask (scenes of up to
-    // 64 nodes; trace_lean.hpp keeps a per-ray candidate mask), else 0
+    // .w of the pair: bits of the node's pre-order subtree [i, skip) as a 64-bit mask (scenes of fewer than
+    // 64 nodes; trace_lean.hpp keeps a per-ray candidate mask)
     uint64_t sub = 0;
-    if (nn <= 64) for (uint32_t k = i; k < nd.skip; k++) sub |= 1ull << k;
-    const uint32_t subLo = uint32_t(sub), subHi = uint32_t(sub >> 32);
+    if (nn < 64) for (uint32_t k = i; k < nd.skip; k++) sub |= 1ull << k;
+    // scenes of 64 nodes and more (trace_lean_chunked.hpp walks the node list per lane): lo.w = the node's skip link, so a
+    // missed box needs no second load
+    const uint32_t subLo = nn < 64 ? uint32_t(sub) : nd.skip, subHi = uint32_t(sub >> 32);
     std::memcpy(&lo.w, &subLo, 4); std::memcpy(&hi.w, &subHi, 4);
     im.nodeWorld[2 * i] = lo; im.nodeWorld[2 * i + 1] = hi;
   }

@@ -1,10 +1,11 @@
-// trace_lean_chunked.hpp — trace_lean.hpp for scenes of 64 nodes and more (device only).
+// trace_lean_walk.hpp — trace_lean.hpp for scenes of many nodes (kLeanWalkNodes and more; device only).
 //
-// Same algorithm; the per-ray scene-node candidate mask covers 64 nodes at a time (candBase), rebuilt when
-// the walk moves on to the next chunk, and a missed node's subtree is jumped over through its skip link.
-// Kept apart from trace_lean.hpp because the three extra words of lane state cost the 80-VGPR kernels
-// spills in their hot loops (measured: 28 -> 37 ms on the reduced C3 workload), which scenes that fit one
-// chunk should not pay.
+// Same algorithm, without the per-ray candidate mask: the mask is built by one wave-uniform pass over ALL node boxes per
+// refill round, which is what a scene of a dozen nodes wants and what makes a scene of a thousand cost a thousand box tests
+// per ray whatever it hits (measured: 20 -> 1064 nodes, same ray count: traversal 8.6 -> 385 ms). Here every lane walks the
+// node list on its own, as the reference's recursion does: the node's padded world box first (the test a mask bit stands
+// for), a miss jumps over the subtree through the node's skip link, a hit goes on to the exact test in the node's space.
+// A ray costs the nodes it visits, not the nodes the scene has.
 //
 // Per ray this is traverse.hpp's TRAV_FAST walk, operation for operation (same scene-node
 // order, same ordered BVH traversal, same leaf order, alpha / transparent candidates hand the
@@ -23,7 +24,7 @@
 // that re-enters the walk after a transformed node is re-read from the path state.
 #pragma once
 #if defined(__HIPCC__)
-#include "trace_lean.hpp"
+#include "trace_lean_chunked.hpp"
 
 namespace yart_hip {
 
@@ -31,7 +32,7 @@ namespace yart_hip {
 // Commit(slot, hit, didHit, attenuation, samplerDim); Retry(pred, slot) appends to the retry queue
 // (wave-wide call). MODE without TRAV_FAST = the general walk (alpha tests inline, no hand-over).
 template <bool NEE, int MODE, class Fetch, class Commit, class Retry>
-__device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk, const uint32_t* queue,
+__device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk, const uint32_t* queue,
                                           uint32_t count, uint32_t* cursor, uint32_t /*nSeg: single cursor here*/, Fetch fetch,
                                           Commit commit, Retry retry, WfTally& tally) {
   constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
@@ -55,13 +56,6 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
   float tEntry = 0.0f;
   // YART_LEAN_LOOP == 3 (trace_lean_bvh3.inc): the leaf a lane has put aside, its entry distance, "the stack ran empty after it"
   uint32_t pendLink = 0; float pendD = 0.0f; bool pendExhausted = false;
-  // Scene nodes this ray can reach at all, 64 at a time: bit k of `cand` = node candBase + k, set if its
-  // padded world box and those of all its ancestors are hit within [0, hit.t] (conservative, see
-  // traverseScene). Built by one wave-uniform pass over the chunk's node boxes; a missed node's subtree
-  // is jumped over through its skip link (skipUntil).
-  unsigned long long cand = 0;
-  uint32_t candBase = 0, skipUntil = 0;
-  bool needMask = false;
 #if defined(YART_COUNT_TRAVERSAL)
   AlphaCtx actx; actx.sampler = nullptr;     // only its counters are used (YART_COUNT)
 #endif
@@ -99,55 +93,31 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
           has = true; inMesh = false; nodeI = 0; didHit = false;
           if (!kFast) { smp = r.smp; attenuation = mk3(1.0f); }
           YART_COUNT(nTrav, 1);
-          candBase = 0; skipUntil = 0;
-          needMask = true;
         }
       }
-    }
-
-    for (;;) {
-    // ------------------------------------------------------------------ (A') candidate masks
-    for (;;) {
-      const unsigned long long need = __ballot(has && needMask);
-      if (need == 0ull) break;
-      const uint32_t b = __shfl(candBase, __ffsll((long long) need) - 1);   // the chunk of this round
-      const bool mine = has && needMask && candBase == b;
-      uint32_t skipLocal = skipUntil;
-      if (mine && !rayIsWorld) { const LeanRay r = fetch(slot); ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true; }
-      unsigned long long m = 0ull;
-      const uint32_t end = b + 64u < sc.nNodes ? b + 64u : sc.nNodes;
-      for (uint32_t n = b; n < end; n++) {                      // wave-uniform addresses
-        const f4 wlo = sc.nodeWorld[2u * n], whi = sc.nodeWorld[2u * n + 1u];
-        if (mine && n >= skipLocal) {
-          WF_PHASE(tally, 4);                                   // candidate-mask box tests
-          const float wmin[3] = {wlo.x, wlo.y, wlo.z}, wmax[3] = {whi.x, whi.y, whi.z};
-          float dw;
-          YART_COUNT(nBox, 1);
-          if (testBox(ray, 0.0f, hit.t + (fabsf(hit.t) * 1e-4f + 1e-3f), wmin, wmax, dw)) m |= 1ull << (n - b);
-          else skipLocal = sc.nodes[n].skip;                      // jump over the subtree
-        }
-      }
-      if (mine) { cand = m; needMask = false; skipUntil = skipLocal; }
     }
 
     // ------------------------------------------------------------------ (B) scene-graph walk
     {
-      while (has && !inMesh && !needMask) {                     // (lanes leave this loop one by one)
+      while (has && !inMesh) {                                  // (lanes leave this loop one by one)
         WF_PHASE(tally, 3);                                     // walk steps
         if (nodeI >= sc.nNodes) {                               // testNode of the root has returned
           commit(slot, hit, didHit, attenuation, smp.dim);
           has = false;
           break;
         }
-        if (nodeI >= candBase + 64u) {               // next chunk of 64 nodes: its mask first
-          candBase = nodeI & ~63u; needMask = true;
-          if (skipUntil < nodeI) skipUntil = nodeI;
-          break;
-        }
-        const unsigned long long rest = cand >> (nodeI - candBase);
-        if (rest == 0ull) { nodeI = candBase + 64u; continue; }
+        // the node's padded world box (conservative: a ray that misses it within [0, hit.t] fails the exact test below, for
+        // this node and for every node of its subtree)
+        if (!rayIsWorld) { const LeanRay r = fetch(slot); ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true; }
         {
-          nodeI += uint32_t(__builtin_ctzll(rest));             // next node the ray can reach
+          const f4 wlo = sc.nodeWorld[2u * nodeI], whi = sc.nodeWorld[2u * nodeI + 1u];
+          const float wmin[3] = {wlo.x, wlo.y, wlo.z}, wmax[3] = {whi.x, whi.y, whi.z};
+          float dw;
+          WF_PHASE(tally, 4);                                   // padded-box tests
+          YART_COUNT(nBox, 1);
+          if (!testBox(ray, 0.0f, hit.t + (fabsf(hit.t) * 1e-4f + 1e-3f), wmin, wmax, dw)) { nodeI = __builtin_bit_cast(uint32_t, wlo.w); continue; }   // (the skip link rides in the box record)
+        }
+        {
           const NodeDev& nd = sc.nodes[nodeI];
           bool skip = false;
           if (!((MODE & TRAV_IDENTITY) || (nd.pad[0] & 1u))) {
@@ -164,7 +134,7 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
             YART_COUNT(nBox, 1);
             if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) skip = true;
           }
-          if (skip) nodeI = nd.skip;                            // (bits of the subtree may remain set: skipped by index)
+          if (skip) nodeI = nd.skip;
           else {
             bool entered = false;
             if (nd.mesh >= 0) {
@@ -189,9 +159,6 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
       }
     }
 
-    if (__ballot(has && needMask) == 0ull) break;               // a lane moved on to the next node chunk: mask, walk again
-    }
-
     if constexpr ((MODE & TRAV_WIDE) != 0) {
 #include "trace_wide_bvh.inc"
     } else {
@@ -211,6 +178,21 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
 #else
   (void)tally;
 #endif
+}
+
+// scenes of at least this many nodes use this form (yart_hip.hip); measured on instanced scenes (tools/many_nodes.py, 960x540x16):
+// instances all over the room, every group box spanning it — 76 nodes: chunked masks 18.0 ms of traversal, this walk 25.2; 267: 74 /
+// 76; 1064: 385 / 246 —, groups of instances that sit together — 267 nodes: 13.1 / 9.8; 1064: 41.5 / 20.4; 4252: 255 / 78
+constexpr uint32_t kLeanWalkNodes = 512;
+
+// the kernels' entry: NODES 0 = one candidate mask (fewer than 64 nodes), 1 = chunked masks, 2 = per-lane walk
+template <bool NEE, int MODE, int NODES, class Fetch, class Commit, class Retry>
+__device__ __forceinline__ void traceLeanAny(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk,
+                                             const uint32_t* queue, uint32_t count, uint32_t* cursor, uint32_t nSeg,
+                                             Fetch fetch, Commit commit, Retry retry, WfTally& tally) {
+  if (NODES == 2) traceLeanWalk<NEE, MODE>(sc, scfg, stk, queue, count, cursor, nSeg, fetch, commit, retry, tally);
+  else if (NODES == 1) traceLeanChunked<NEE, MODE>(sc, scfg, stk, queue, count, cursor, nSeg, fetch, commit, retry, tally);
+  else traceLean<NEE, MODE>(sc, scfg, stk, queue, count, cursor, nSeg, fetch, commit, retry, tally);
 }
 
 }  // namespace yart_hip

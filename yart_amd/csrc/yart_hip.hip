@@ -34,6 +34,7 @@
 #include "wavefront.hpp"
 #include "trace_lean.hpp"
 #include "trace_lean_chunked.hpp"
+#include "trace_lean_walk.hpp"
 #include "tonemap.hpp"
 
 using namespace yart_hip;
@@ -482,27 +483,29 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // TRAV_WIDE: the lean kernels walk the 4-wide records (wide_bvh.hpp, trace_wide_bvh.inc)
   const bool wide = refill && (effFlags & YART_FLAG_WIDE_BVH) != 0;
   const bool wideE = wide && !(effFlags & 512u), wideS = wide && !(effFlags & 256u);   // (debug: 256 = closest-hit rays only, 512 = shadow rays only)
+  // 0: one candidate mask per ray, 1: chunked masks (64 nodes and more), 2: per-lane walk of the node list (kLeanWalkNodes and more)
+  const int nodesForm = !chunked ? 0 : (s.host.nodes.size() >= kLeanWalkNodes || (effFlags & 65536u)) ? 2 : 1;   // (debug bit 65536: the walk from 64 nodes on)
+#define YART_PICK_LEAN(KERNEL, M)                                                                                             \
+  (nodesForm == 2 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 2> : KERNEL<(M), 2>)                                                 \
+   : nodesForm == 1 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 1> : KERNEL<(M), 1>) : (ident ? KERNEL<(M) | TRAV_IDENTITY, 0> : KERNEL<(M), 0>))
   auto pickExtend = [&]() -> void (*)(WfArgs) {
     if (!refill) return ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
-    if (wideE) return chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, true> : k_wf_extend_lean<TRAV_FAST | TRAV_WIDE, true>)
-                             : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, false> : k_wf_extend_lean<TRAV_FAST | TRAV_WIDE, false>);
-    return chunked ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_extend_lean<TRAV_FAST, true>)
-                   : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_extend_lean<TRAV_FAST, false>);
+    if (wideE) return YART_PICK_LEAN(k_wf_extend_lean, TRAV_FAST | TRAV_WIDE);
+    return YART_PICK_LEAN(k_wf_extend_lean, TRAV_FAST);
   };
   auto pickShadow = [&]() -> void (*)(WfArgs) {
     if (!refill) return ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>;
-    if (wideS) return chunked ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, true> : k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE, true>)
-                             : (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY | TRAV_WIDE, false> : k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE, false>);
-    return chunked ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, true> : k_wf_shadow_lean<TRAV_FAST, true>)
-                   : (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_IDENTITY, false> : k_wf_shadow_lean<TRAV_FAST, false>);
+    if (wideS) return YART_PICK_LEAN(k_wf_shadow_lean, TRAV_FAST | TRAV_WIDE);
+    return YART_PICK_LEAN(k_wf_shadow_lean, TRAV_FAST);
   };
+#undef YART_PICK_LEAN
   auto kExtendFast = pickExtend();
   auto kShadowFast = pickShadow();
   // debug bit 4096: camera rays (bounce 0) through the one-ray-per-lane kernel, see the launch below (tools/b0_ab.py)
   const bool cameraOneRay = refill && !wideE && (effFlags & 4096u);
   auto kExtendCamera = ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
-  auto kRetryE = chunked ? k_wf_extend_retry_lean<true> : k_wf_extend_retry_lean<false>;
-  auto kRetryS = chunked ? k_wf_shadow_retry_lean<true> : k_wf_shadow_retry_lean<false>;
+  auto kRetryE = nodesForm == 2 ? k_wf_extend_retry_lean<2> : nodesForm == 1 ? k_wf_extend_retry_lean<1> : k_wf_extend_retry_lean<0>;
+  auto kRetryS = nodesForm == 2 ? k_wf_shadow_retry_lean<2> : nodesForm == 1 ? k_wf_shadow_retry_lean<1> : k_wf_shadow_retry_lean<0>;
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
   const int gridExtendFast = persistentGrid(s, reinterpret_cast<const void*>(kExtendFast), 8);
   const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);

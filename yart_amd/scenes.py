@@ -583,7 +583,8 @@ def write_params(path, p, threads=None, probe_pixels=None, **override):
         f.write("\n".join(lines) + "\n")
 
 
-def instances(width=96, height=96, spp=4, depth=4, n_instances=70, groups=4, seed=7):
+def instances(width=96, height=96, spp=4, depth=4, n_instances=70, groups=4, seed=7, child_extent=3.5, group_extent=1.0,
+              scale=(0.3, 0.9)):
     """Cornell room + `n_instances` instanced unit boxes under `groups` transformed group nodes
     (rotation + non-uniform scale + translation, nested two levels): exercises the scene-graph walk
     (skip links, nested transform chains, world-space node culling, per-ray node candidate masks —
@@ -603,14 +604,15 @@ def instances(width=96, height=96, spp=4, depth=4, n_instances=70, groups=4, see
         return m.astype(np.float32), np.linalg.inv(m).astype(np.float32)
     group_nodes = []
     for g in range(groups):
-        f, i = trs((rng.uniform(-1, 1), rng.uniform(0.5, 2.0), rng.uniform(-1, 1)), rng.uniform(-0.5, 0.5), (1.0, 1.0, 1.0))
+        f, i = trs((rng.uniform(-group_extent, group_extent), rng.uniform(0.5, 2.0) if group_extent == 1.0 else rng.uniform(0.5, 5.5),
+                    rng.uniform(-group_extent, group_extent)), rng.uniform(-0.5, 0.5), (1.0, 1.0, 1.0))
         group_nodes.append((g, f, i))
     per = [n_instances // groups + (1 if g < n_instances % groups else 0) for g in range(groups)]
     for g, f, i in group_nodes:                       # pre-order: group, then its instances
         gi = s.add_node(-1, 0, f, i)
         for _ in range(per[g]):
-            f2, i2 = trs((rng.uniform(-3.5, 3.5), rng.uniform(0.0, 6.0), rng.uniform(-3.5, 3.5)), rng.uniform(0, 6.28),
-                         tuple(rng.uniform(0.3, 0.9, 3)))
+            f2, i2 = trs((rng.uniform(-child_extent, child_extent), rng.uniform(0.0, 6.0) if child_extent == 3.5 else rng.uniform(-child_extent, child_extent),
+                          rng.uniform(-child_extent, child_extent)), rng.uniform(0, 6.28), tuple(rng.uniform(scale[0], scale[1], 3)))
             s.add_node(cube, gi, f2, i2)
     s.create_area_lights()
     return s, p

@@ -340,7 +340,14 @@ int resolveDevice(int device) {
 // the device build of one mesh's BVH (same bytes as the host build; a mesh it refuses — NaN coordinates — is left to the host)
 static bool deviceMeshBvh(void* ctx, const float* positions, uint32_t nVerts, const uint32_t* faces, uint32_t stride, uint32_t nFaces,
                           std::vector<BvhNode>& nodes, std::vector<uint32_t>& indices) {
-  return devbvh::build(*static_cast<int*>(ctx), positions, nVerts, faces, stride, nFaces, nodes, indices, nullptr);
+  // any failure of the device build (out of device memory for its scratch arrays, ...) leaves the mesh to the host builder
+  try {
+    return devbvh::build(*static_cast<int*>(ctx), positions, nVerts, faces, stride, nFaces, nodes, indices, nullptr);
+  } catch (const std::exception&) {
+    (void)hipGetLastError();
+    nodes.clear(); indices.clear();
+    return false;
+  }
 }
 YartScene* createScene(const YartSceneDesc& desc, int device, uint32_t sceneFlags = 0) {
   int dev = resolveDevice(device);

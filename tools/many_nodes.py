@@ -10,7 +10,8 @@ for n in (16, 60, 70, 250, 1000, 4000):
     kw = dict(child_extent=0.35, group_extent=3.0, scale=(0.04, 0.12)) if compact else {}
     scene, p = scenes.instances(960, 540, 16, 4, n_instances=n, groups=max(2, n // 16), **kw)
     ds = api.DeviceScene(scene, device=0)
-    ds.render(p)
-    img, st = ds.render(p)
+    fl = int(os.environ.get("FLAGS", 0))       # 65536: per-lane walk, 131072: top-level hierarchy, from 64 nodes on
+    ds.render(p, flags=fl)
+    img, st = ds.render(p, flags=fl)
     rays = st["rays"] if "rays" in st else 0
     print(f"{len(scene.nodes):5d} nodes: total {st['ms_device']:8.1f} ms  extend {st['ms_extend']:7.1f}  connect {st['ms_connect']:7.1f}  shade {st['ms_shade']:7.1f}  rays {rays}", flush=True)

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/yart_hip.h"
@@ -50,6 +51,7 @@ struct HostImage {
   std::vector<float> envData;
   std::vector<uint32_t> envGuide;                  // CDF search guide tables (EnvDev::guideOffset)
   std::vector<f4> nodeWorld;                       // conservative world-space node boxes (traverse.hpp)
+  std::vector<TlasNode> tlas;                      // spatial hierarchy over the mesh nodes' boxes (scenes of 64 nodes and more)
   std::vector<uint32_t> infiniteLights, areaLights;
   std::vector<float> areaPowerCdf;
   std::vector<float> lut;                          // LutDev layout (incl. Sobol matrix bits)
@@ -72,6 +74,7 @@ struct HostImage {
     s.materials = materials.data(); s.textures = textures.data(); s.texU8 = texU8.data();
     s.texF32 = texF32.data(); s.lights = lights.data(); s.envs = envs.data(); s.envData = envData.data();
     s.envGuide = envGuide.data(); s.nodeWorld = nodeWorld.data();
+    s.tlas = tlas.data(); s.nTlas = uint32_t(tlas.size()); s.nodeBits = nullptr; s.nodeBitWords = 0;
     s.infiniteLights = infiniteLights.data(); s.areaLights = areaLights.data();
     s.areaPowerCdf = areaPowerCdf.data(); s.lut = lut.data();
     s.nNodes = uint32_t(nodes.size()); s.nLights = nLights;
@@ -359,6 +362,40 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
     std::memcpy(&lo.w, &subLo, 4); std::memcpy(&hi.w, &subHi, 4);
     im.nodeWorld[2 * i] = lo; im.nodeWorld[2 * i + 1] = hi;
   }
+
+  // ---- spatial hierarchy over the mesh nodes' padded world boxes (scenes of 64 nodes and more): median splits of the box
+  // centres along the widest axis, one node per leaf. Any tree would do: a ray's query only has to return every mesh node whose
+  // box it hits (trace_lean_tlas.hpp), the exact tests then run in the reference's pre-order.
+  if (nn >= 64) {
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < nn; i++) if (im.nodes[i].mesh >= 0) ids.push_back(i);
+    if (!ids.empty()) {
+      auto centre = [&](uint32_t n, int c) { return 0.5f * ((&im.nodeWorld[2 * n].x)[c] + (&im.nodeWorld[2 * n + 1].x)[c]); };
+      im.tlas.resize(2 * ids.size() - 1);
+      uint32_t used = 1;
+      std::function<void(uint32_t, uint32_t, uint32_t)> build = [&](uint32_t at, uint32_t lo, uint32_t hi) {
+        TlasNode t{};
+        for (int c = 0; c < 3; c++) { t.lo[c] = kInf; t.hi[c] = -kInf; }
+        float cmin[3] = {kInf, kInf, kInf}, cmax[3] = {-kInf, -kInf, -kInf};
+        for (uint32_t k = lo; k < hi; k++)
+          for (int c = 0; c < 3; c++) {
+            t.lo[c] = std::min(t.lo[c], (&im.nodeWorld[2 * ids[k]].x)[c]); t.hi[c] = std::max(t.hi[c], (&im.nodeWorld[2 * ids[k] + 1].x)[c]);
+            cmin[c] = std::min(cmin[c], centre(ids[k], c)); cmax[c] = std::max(cmax[c], centre(ids[k], c));
+          }
+        if (hi - lo == 1) { t.a = ids[lo]; t.b = 1; im.tlas[at] = t; return; }
+        int axis = 0;
+        for (int c = 1; c < 3; c++) if (cmax[c] - cmin[c] > cmax[axis] - cmin[axis]) axis = c;
+        const uint32_t mid = lo + (hi - lo) / 2;
+        std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi,
+                         [&](uint32_t x, uint32_t y) { const float cx = centre(x, axis), cy = centre(y, axis); return cx < cy || (cx == cy && x < y); });
+        t.a = used; t.b = 0; used += 2;
+        im.tlas[at] = t;
+        build(t.a, lo, mid); build(t.a + 1, mid, hi);
+      };
+      build(0, 0, uint32_t(ids.size()));
+    }
+  }
+  if (im.tlas.empty()) im.tlas.resize(1);
 
   // ---- lights (light.cpp, light-sampler.cpp:32-50) ------------------------------
   for (uint32_t i = 0; i < d.n_lights; i++) {

@@ -100,6 +100,9 @@ struct NodeDev {           // core/scene.hpp:11-64
   int32_t parent; uint32_t depth; uint32_t pad[2];
 };
 
+// inner: a = left child (right = a + 1), b = 0; leaf: a = scene node, b = 1. Root = node 0.
+struct TlasNode { float lo[3]; uint32_t a; float hi[3]; uint32_t b; };
+
 struct LightDev {          // core/light.hpp
   uint32_t type; int32_t mesh; uint32_t tri; uint32_t twoSided;
   f3 emission; float area;         // AreaLight::m_area (of the transformed triangle)
@@ -161,6 +164,12 @@ struct SceneDev {
   const float* envData;
   const uint32_t* envGuide;
   const f4* nodeWorld;       // 2 per scene node: padded WORLD-space AABB of the node's subtree (min, max)
+  // scenes of many nodes (trace_lean_tlas.hpp): a spatial hierarchy over the mesh nodes' nodeWorld boxes — a filter only, the
+  // exact tests still run in the reference's pre-order — and the lanes' node bitsets (scratch, set per launch): nodeBitWords
+  // 64-bit words per lane, word w of thread t at nodeBits[w * threads + t]
+  const struct TlasNode* tlas;
+  unsigned long long* nodeBits;
+  uint32_t nTlas, nodeBitWords;
   const uint32_t* infiniteLights;   // indices into lights
   const uint32_t* areaLights;       // indices into lights
   const float* areaPowerCdf;        // m_lightPowers, light-sampler.cpp:43-47

@@ -185,15 +185,5 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
 // 76; 1064: 385 / 246 —, groups of instances that sit together — 267 nodes: 13.1 / 9.8; 1064: 41.5 / 20.4; 4252: 255 / 78
 constexpr uint32_t kLeanWalkNodes = 512;
 
-// the kernels' entry: NODES 0 = one candidate mask (fewer than 64 nodes), 1 = chunked masks, 2 = per-lane walk
-template <bool NEE, int MODE, int NODES, class Fetch, class Commit, class Retry>
-__device__ __forceinline__ void traceLeanAny(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk,
-                                             const uint32_t* queue, uint32_t count, uint32_t* cursor, uint32_t nSeg,
-                                             Fetch fetch, Commit commit, Retry retry, WfTally& tally) {
-  if (NODES == 2) traceLeanWalk<NEE, MODE>(sc, scfg, stk, queue, count, cursor, nSeg, fetch, commit, retry, tally);
-  else if (NODES == 1) traceLeanChunked<NEE, MODE>(sc, scfg, stk, queue, count, cursor, nSeg, fetch, commit, retry, tally);
-  else traceLean<NEE, MODE>(sc, scfg, stk, queue, count, cursor, nSeg, fetch, commit, retry, tally);
-}
-
 }  // namespace yart_hip
 #endif  // __HIPCC__

@@ -35,6 +35,7 @@
 #include "trace_lean.hpp"
 #include "trace_lean_chunked.hpp"
 #include "trace_lean_walk.hpp"
+#include "trace_lean_tlas.hpp"
 #include "tonemap.hpp"
 
 using namespace yart_hip;
@@ -277,7 +278,7 @@ struct YartScene {
   DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<Wide4> wideNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32;
-  DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld;
+  DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld; DevBuf<TlasNode> tlas; DevBuf<unsigned long long> nodeBits;
   DevBuf<uint32_t> infiniteLights, areaLights; DevBuf<float> areaPowerCdf; DevBuf<float> lut;
   DevBuf<uint8_t> matClass;                // host_scene.hpp::lobeClass per material
   // render scratch (grown on demand, reused across calls)
@@ -306,7 +307,7 @@ void uploadScene(YartScene& s) {
   s.triLight.upload(h.triLight); s.vPos.upload(h.vPos); s.vNormal.upload(h.vNormal);
   s.vTangent.upload(h.vTangent); s.vUV.upload(h.vUV); s.meshes.upload(h.meshes); s.nodes.upload(h.nodes);
   s.materials.upload(h.materials); s.textures.upload(h.textures); s.texU8.upload(h.texU8);
-  s.texF32.upload(h.texF32); s.lights.upload(h.lights); s.envs.upload(h.envs); s.envData.upload(h.envData); s.envGuide.upload(h.envGuide); s.nodeWorld.upload(h.nodeWorld);
+  s.texF32.upload(h.texF32); s.lights.upload(h.lights); s.envs.upload(h.envs); s.envData.upload(h.envData); s.envGuide.upload(h.envGuide); s.nodeWorld.upload(h.nodeWorld); s.tlas.upload(h.tlas);
   s.infiniteLights.upload(h.infiniteLights); s.areaLights.upload(h.areaLights);
   s.areaPowerCdf.upload(h.areaPowerCdf); s.lut.upload(h.lut);
   {
@@ -320,7 +321,7 @@ void uploadScene(YartScene& s) {
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
   d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.lights = s.lights.p; d.envs = s.envs.p;
-  d.envData = s.envData.p; d.envGuide = s.envGuide.p; d.nodeWorld = s.nodeWorld.p; d.infiniteLights = s.infiniteLights.p; d.areaLights = s.areaLights.p;
+  d.envData = s.envData.p; d.envGuide = s.envGuide.p; d.nodeWorld = s.nodeWorld.p; d.tlas = s.tlas.p; d.nTlas = h.tlas.size() > 1 || (h.tlas.size() == 1 && h.tlas[0].b) ? uint32_t(h.tlas.size()) : 0u; d.infiniteLights = s.infiniteLights.p; d.areaLights = s.areaLights.p;
   d.areaPowerCdf = s.areaPowerCdf.p; d.lut = s.lut.p;
   s.dev = d;
 }
@@ -490,10 +491,14 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // TRAV_WIDE: the lean kernels walk the 4-wide records (wide_bvh.hpp, trace_wide_bvh.inc)
   const bool wide = refill && (effFlags & YART_FLAG_WIDE_BVH) != 0;
   const bool wideE = wide && !(effFlags & 512u), wideS = wide && !(effFlags & 256u);   // (debug: 256 = closest-hit rays only, 512 = shadow rays only)
-  // 0: one candidate mask per ray, 1: chunked masks (64 nodes and more), 2: per-lane walk of the node list (kLeanWalkNodes and more)
-  const int nodesForm = !chunked ? 0 : (s.host.nodes.size() >= kLeanWalkNodes || (effFlags & 65536u)) ? 2 : 1;   // (debug bit 65536: the walk from 64 nodes on)
+  // 64 nodes and more: candidate windows from the top-level hierarchy (3; measured the fastest form at every size from 65 to 4252
+  // nodes, profiles/r2_many_nodes.txt). Without it (no mesh nodes, more than 16384 nodes = 2 KB of bitset per lane, or debug bit
+  // 262144): chunked masks below kLeanWalkNodes nodes, the per-lane walk from there on (debug bit 65536: the walk at any size)
+  const bool tlasOk = s.dev.nTlas != 0u && s.host.nodes.size() <= 16384u && !(effFlags & (262144u | 65536u));
+  const int nodesForm = !chunked ? 0 : tlasOk ? 3 : ((effFlags & 65536u) || s.host.nodes.size() >= kLeanWalkNodes) ? 2 : 1;
 #define YART_PICK_LEAN(KERNEL, M)                                                                                             \
-  (nodesForm == 2 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 2> : KERNEL<(M), 2>)                                                 \
+  (nodesForm == 3 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 3> : KERNEL<(M), 3>)                                                 \
+   : nodesForm == 2 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 2> : KERNEL<(M), 2>)                                               \
    : nodesForm == 1 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 1> : KERNEL<(M), 1>) : (ident ? KERNEL<(M) | TRAV_IDENTITY, 0> : KERNEL<(M), 0>))
   auto pickExtend = [&]() -> void (*)(WfArgs) {
     if (!refill) return ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
@@ -511,8 +516,8 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // debug bit 4096: camera rays (bounce 0) through the one-ray-per-lane kernel, see the launch below (tools/b0_ab.py)
   const bool cameraOneRay = refill && !wideE && (effFlags & 4096u);
   auto kExtendCamera = ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
-  auto kRetryE = nodesForm == 2 ? k_wf_extend_retry_lean<2> : nodesForm == 1 ? k_wf_extend_retry_lean<1> : k_wf_extend_retry_lean<0>;
-  auto kRetryS = nodesForm == 2 ? k_wf_shadow_retry_lean<2> : nodesForm == 1 ? k_wf_shadow_retry_lean<1> : k_wf_shadow_retry_lean<0>;
+  auto kRetryE = nodesForm == 3 ? k_wf_extend_retry_lean<3> : nodesForm == 2 ? k_wf_extend_retry_lean<2> : nodesForm == 1 ? k_wf_extend_retry_lean<1> : k_wf_extend_retry_lean<0>;
+  auto kRetryS = nodesForm == 3 ? k_wf_shadow_retry_lean<3> : nodesForm == 2 ? k_wf_shadow_retry_lean<2> : nodesForm == 1 ? k_wf_shadow_retry_lean<1> : k_wf_shadow_retry_lean<0>;
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
   const int gridExtendFast = persistentGrid(s, reinterpret_cast<const void*>(kExtendFast), 8);
   const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);
@@ -528,6 +533,12 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   gridMax = std::max(gridMax, gridExtendCamera);
   gridMax = std::max(gridMax, std::max(gridRetryE, gridRetryS));
   s.spill.ensure(size_t(gridMax) * kBlock * kSpillDepthMax);
+  // the lanes' node bitsets of the top-level-hierarchy form (trace_lean_tlas.hpp): all zero between launches
+  const uint32_t nodeBitWords = nodesForm == 3 ? uint32_t((s.host.nodes.size() + 63u) / 64u) : 0u;
+  if (nodeBitWords) {
+    const size_t need = size_t(gridMax) * kBlock * nodeBitWords;
+    if (s.nodeBits.n < need) { s.nodeBits.ensure(need); HIP_CHECK(hipMemsetAsync(s.nodeBits.p, 0, need * 8, stream)); }
+  }
 
   // Batch = as many pixels (x all samples of a wave) as half of the device memory that is free — or
   // already held by this scene's scratch buffers — allows, up to kWfMaxPaths: 172 B per path (144 B of
@@ -638,6 +649,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         a.pixels = s.pixels.p + c0; a.nPaths = n * uint32_t(waveSamples); a.spp = uint32_t(waveSamples);
         a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p; a.stats = s.counters.p; a.spill = s.spill.p;
         a.matClass = s.matClass.p;
+        a.sc.nodeBits = s.nodeBits.p; a.sc.nodeBitWords = nodeBitWords;
         if (compact) {
           for (int t = 0; t < 2; t++) {
             f4** f = &a.tail[t].ray0;                  // the nine pointers of WfState, in declaration order

@@ -43,6 +43,9 @@ using namespace yart_hip;
 namespace {
 
 constexpr int kBlock = 256;            // 4 waves per workgroup
+#ifndef YART_STREAM_BLOCKS
+#define YART_STREAM_BLOCKS 8           // workgroups per CU of the streaming kernels (generate, post, compact); shade + post stage at 1080p x 64 spp: 4 -> 105.5, 8 -> 106.1, 16 -> 106.4, 32 -> 106.6 ms
+#endif
 constexpr int kLdsStack = 24;          // traversal stack entries kept in LDS per lane (8 B each)
 constexpr int kSpillDepth = int(kRefStackDepth) - kLdsStack;
 constexpr int kSpillDepthMax = int(kRefStackDepth);   // spill area sized for the shallowest LDS stack
@@ -665,7 +668,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         const uint32_t init[WC_COUNT] = {a.nPaths, 0, 0, 0, 0, 0, 0, 0};
         HIP_CHECK(hipMemcpyAsync(s.wfCounters.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
         tShade.begin(stream);
-        hipLaunchKernelGGL(k_wf_generate, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL(k_wf_generate, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
         HIP_CHECK(hipGetLastError());
         tShade.end(stream);
         for (uint32_t bounce = 0; bounce < rc.maxDepth; bounce++) {
@@ -709,7 +712,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           HIP_CHECK(hipGetLastError());
           tConnect.end(stream);
           tShade.begin(stream);
-          hipLaunchKernelGGL(k_wf_post, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
+          hipLaunchKernelGGL(k_wf_post, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
           HIP_CHECK(hipGetLastError());
           tShade.end(stream);
           hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
@@ -717,7 +720,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           std::swap(a.qA, a.qB);
           if (compact && bounce >= 1 && bounce + 1 < rc.maxDepth) {     // Russian roulette starts thinning at depth 2
             tShade.begin(stream);
-            hipLaunchKernelGGL(k_wf_compact, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(k_wf_compact, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
             hipLaunchKernelGGL(k_wf_compact_commit, dim3(1), dim3(64), 0, stream, a);
             HIP_CHECK(hipGetLastError());
             tShade.end(stream);

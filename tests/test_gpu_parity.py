@@ -244,11 +244,13 @@ def test_edge_cases_vs_oracle_live(api, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(ORACLE_BIN), reason="oracle restatement not built")
-@pytest.mark.parametrize("n_instances", [20, 58, 70, 250, 600])
+@pytest.mark.parametrize("n_instances", [20, 58, 70, 250, 600, 4200])
 def test_instanced_scene_vs_oracle_live(api, tmp_path, n_instances):
     """Scene-graph walk: nested transformed group / instance nodes. 58 instances = exactly 64
     nodes (one chunk of the per-ray node candidate mask of trace_lean.hpp), 70 = 76 nodes (two
-    chunks), 250 = 256 nodes (four); every pipeline must reproduce the oracle."""
+    chunks), 250 = 256 nodes (four); 600 and 4200 instances: the sizes at which the forms without the top-level hierarchy
+    switch to the per-lane walk, and at which the hierarchy's per-lane bitset needs word groups (more than 4096 nodes:
+    trace_lean_tlas.hpp); every pipeline must reproduce the oracle."""
     from yart_amd import scenes
     s, p = scenes.instances(96, 96, 4, 4, n_instances=n_instances)
     sp, pp, out = tmp_path / "i.yscn", tmp_path / "i.txt", tmp_path / "i.f32"

@@ -3,14 +3,23 @@
 Sponza-class scene at 1920x1080, 256 spp, 8 bounces (BASELINE.json configs[2]), tiles
 sharded across N MI355X with an RCCL reduce of the framebuffer (configs[3] scheme).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` is what decides the number of ranks. Started WITHOUT torchrun's environment and N > 1, this process
+launches the N ranks itself (`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, BEFORE
+it has touched the GPU), relays rank 0's JSON line and exits with the child's code; it refuses (exit 2) when fewer
+than N devices are visible. Started BY torchrun, WORLD_SIZE must equal --gpus (exit 2 otherwise): `n_gpus` in the
+line is the world size RCCL actually ran with, never a number taken from the command line alone.
+`--dry-launch` rehearses exactly that launch path without a GPU: N gloo ranks reduce synthetic frames cut by the
+library's tile partition (tests/test_dist_cpu.py).
 
 A "step" is one complete render of the frame (all 256 spp of every pixel, GMoN, blend,
 and — for N > 1 — the reduce of the per-rank framebuffers to rank 0). Scene upload and
 BVH build are outside the timed region; the framebuffer stays in HBM (a torch tensor).
 
-Rank 0 prints ONE JSON line (DESIGN.md §5 explains every field). At N = 1 the line also carries
+Rank 0 prints ONE JSON line (DESIGN.md §5 explains every field). The line also carries (at N > 1 for rank 0's share of the frame,
+with `per_rank` = every rank's device time and stage times and `reduce_ms` = the RCCL reduce per step)
   parity        the same scene / camera / depth at `--cpu-spp` samples rendered on the GPU and compared with the
                 frame the CPU baseline leg just rendered (RMSE in linear HDR, identical-pixel fraction); the bench
                 exits with status 3 if RMSE >= 1e-3 (every timed run is checked)
@@ -62,6 +71,8 @@ def parse():
     ap.add_argument("--ref-order-spp", type=int, default=1, help="spp of the oracle run that counts box / triangle tests in the reference's traversal order")
     ap.add_argument("--flags", type=int, default=0, help="YART_FLAG_* pipeline variant (A/B experiments)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one un-timed step, no torch (run under rocprofv3 --pmc)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="no GPU: start the --gpus N ranks with gloo and reduce synthetic frames (launch-path rehearsal)")
     ap.add_argument("--keep-pmc", default="", help="directory to keep the raw counter csv files in (e.g. profiles/...)")
     return ap.parse_args()
 
@@ -194,16 +205,86 @@ def cpu_baseline(scene, p, args):
     return (entry, ref_order), frame
 
 
+def self_launch(args):
+    """--gpus N > 1 (or --dry-launch) without torchrun's environment: start the N ranks as children of THIS process,
+    which has not touched the GPU, relay their output (rank 0 prints the JSON line) and return the launcher's code."""
+    import socket
+    n = args.gpus
+    if n < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        return 2
+    if not args.dry_launch and not os.environ.get("YART_BENCH_ONE_DEVICE"):
+        import torch
+        have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} but only {have} HIP device(s) are visible: refusing to measure fewer GPUs than asked\n")
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable or "python3", "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_rank(args, rank, world):
+    """One rank of --dry-launch: gloo on the CPU, a synthetic frame (a function of the pixel) cut by the library's
+    block partition, the same reduce the GPU path does, checked on rank 0. No GPU, no library call."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from yart_amd import dist as yd
+    dist.init_process_group("gloo")
+    W, H = min(args.width, 256), min(args.height, 144)
+    ys, xs = np.mgrid[0:H, 0:W]
+    full = np.stack([xs * 0.25 + 1.0, ys * 0.5 + 2.0, (xs ^ ys) * 1.0, np.ones_like(xs, dtype=np.float64)], -1).astype(np.float32)
+    block = 16 if world > 1 else 64
+    mask = yd.pixel_mask(W, H, block, rank, world)
+    fb = torch.from_numpy(np.where(mask[..., None], full, 0.0).astype(np.float32))
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        part = fb.clone()
+        yd.merge(part, 0)
+    dt = time.perf_counter() - t0
+    counts = [None] * world
+    dist.all_gather_object(counts, int(mask.sum()))
+    status = 0
+    if rank == 0:
+        ok = bool(np.array_equal(part.numpy().view(np.uint32), full.view(np.uint32)))
+        print(json.dumps({"dry_launch": True, "n_gpus": dist.get_world_size(), "backend": "gloo", "steps": args.steps,
+                          "frame": [W, H], "block": block, "pixels_per_rank": counts, "merged_equals_full_frame": ok,
+                          "reduce_ms": round(dt / max(1, args.steps) * 1e3, 3), "data": "synthetic frames, no GPU"}), flush=True)
+        status = 0 if ok and sum(counts) == W * H else 4
+    dist.barrier()
+    dist.destroy_process_group()
+    return status
+
+
+STAGE_KEYS = ("ms_device", "ms_extend", "ms_extend_lean", "ms_connect", "ms_shadow_lean", "ms_shade", "ms_shade_kernel", "ms_gmon")
+
+
 def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus != 1 or args.dry_launch):
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a mismatched n_gpus\n")
+        return 2
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_launch:
+        return dry_rank(args, rank, world)
 
-    # counter passes first: child processes, started before this process has initialised the GPU
+    # counter passes first: child processes, started before this process has initialised the GPU. At N > 1 they are
+    # left out (a profiler child on GPU 0 while seven other ranks hold their devices is not a combination to try on
+    # a shared node): `traffic` is then null and the N = 1 line / profiles/ carry the memory-side bytes.
     pmc = None
     if world == 1 and not args.no_roofline and not args.no_pmc and not under_profiler():
         pmc = pmc_traffic(args)
@@ -219,12 +300,17 @@ def main():
     backend = os.environ.get("YART_BENCH_BACKEND", "nccl")
     if os.environ.get("YART_BENCH_ONE_DEVICE"):
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        sys.stderr.write(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)\n")
+        return 2
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != world:
+            raise SystemExit("bench.py: the process group's world size differs from WORLD_SIZE")
 
     scene, p = workload(args)
     W, H = p["size"]
@@ -237,16 +323,27 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     last = {}
+    reduce_ev = []
 
-    def step():
+    def merge_frame(t):
+        # non-owned blocks are exactly 0 on every rank -> the sum is the merged frame
+        if backend == "nccl":
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)      # gloo has no CUDA reduce
+
+    def step(timed=False):
         st = dscene.render_into(fb, p, rank=rank, world_size=world, flags=args.flags, stream=stream)
         last.update(st)
         if world > 1:
-            # non-owned tiles are exactly 0 on every rank -> the sum is the merged frame
-            if backend == "nccl":
-                dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+            if timed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                merge_frame(fb)
+                b.record()
+                reduce_ev.append((a, b))
             else:
-                dist.all_reduce(fb, op=dist.ReduceOp.SUM)      # gloo has no CUDA reduce
+                merge_frame(fb)
 
     def fence():
         if world > 1:
@@ -259,60 +356,102 @@ def main():
     t0 = time.perf_counter()
     # per-kernel HIP-event time on the render stream (YartStats), summed over the timed steps
     kern = {"k_wf_shade": [0.0, 0], "k_wf_extend_lean": [0.0, 0], "k_wf_shadow_lean": [0.0, 0]}
+    stage_sum = {k: 0.0 for k in STAGE_KEYS}
     for _ in range(args.steps):
-        step()
+        step(timed=True)
         for k, (ms, n) in (("k_wf_shade", ("ms_shade_kernel", "launches_shade_kernel")),
                            ("k_wf_extend_lean", ("ms_extend_lean", "launches_extend_lean")),
                            ("k_wf_shadow_lean", ("ms_shadow_lean", "launches_shadow_lean"))):
             kern[k][0] += last[ms]; kern[k][1] += last[n]
+        for k in STAGE_KEYS:
+            stage_sum[k] += last[k]
     fence()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return 0
+        # every rank's own device time and stage times (per step) and the time its stream spent in the reduce
+        mine = {k: round(stage_sum[k] / max(1, args.steps), 3) for k in STAGE_KEYS}
+        mine["reduce_ms"] = round(sum(a.elapsed_time(b) for a, b in reduce_ev) / max(1, len(reduce_ev)), 3)
+        mine["rank"] = rank
+        mine["samples"] = int(last.get("samples", 0))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     total_samples = W * H * p["spp"] * args.steps
     value = total_samples / dt * 1e-6
+    n_ranks = dist.get_world_size() if world > 1 else 1
     out = {
         "metric": "Msamples/sec (W*H*spp/s), Sponza-class 1080p 8-bounce",
-        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_ranks, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "sponza_class (generated atrium, %d triangles, env-lit) %dx%d, %d spp, %d bounces"
                                % (scene.n_triangles, W, H, p["spp"], p["depth"]),
                    "pipeline": "megakernel" if args.flags & 1 else "wavefront", "tiles": f"{shard or 64}x{shard or 64} pixel blocks, Morton order, round-robin over ranks",
-                   "parallelism": f"tiles/{world}", "pipeline_flags": int(last.get("pipeline_flags", args.flags))},
+                   "parallelism": f"tiles/{n_ranks}: one process per GPU (torch.distributed, backend {backend if world > 1 else 'none'}), "
+                                  "blocks sharded by rank inside the library, one reduce(SUM) of the frame to rank 0 per step",
+                   "pipeline_flags": int(last.get("pipeline_flags", args.flags))},
         "rays_per_step": int(last.get("rays", 0)),
     }
+    if per_rank is not None:
+        slow = max(per_rank, key=lambda r: r["ms_device"])
+        ideal = sum(r["ms_device"] for r in per_rank) / len(per_rank)
+        out["rays_per_step"] = None          # (rank 0's share only is known here; see per_rank samples)
+        out["per_rank"] = per_rank
+        out["slowest_rank"] = {"rank": slow["rank"], "stage_ms_per_step": {k: slow[k] for k in STAGE_KEYS},
+                               "ms_device_over_mean": round(slow["ms_device"] / ideal, 4) if ideal > 0 else None}
+        out["reduce_ms"] = max(r["reduce_ms"] for r in per_rank)
     status = 0
 
     # ---- CPU legs: baseline timing, parity frame, reference-order counters --------------------------
+    # (rank 0 only; at N > 1 the other ranks wait in the parity render's reduce. `cpu_baseline` is an N = 1 entry; at
+    # N > 1 the leg still runs, for the frame the merged GPU frame is compared with)
     ref_order = None
-    if not args.no_cpu_baseline and world == 1:
-        cb, ref_frame = cpu_baseline(scene, p, args)
-        if cb:
-            out["cpu_baseline"], ref_order = cb
-            img, _ = dscene.render(dict(p, spp=args.cpu_spp), flags=args.flags)
-            e = float(np.sqrt(np.mean((np.nan_to_num(img[..., :3]).astype(np.float64) - np.nan_to_num(ref_frame[..., :3])) ** 2)))
-            same = float(np.mean(np.all(img.view(np.uint32) == ref_frame.view(np.uint32), axis=-1)))
-            out["parity"] = {"rmse": e, "identical_pixel_fraction": round(same, 6), "tolerance": RMSE_TOL, "ok": bool(e < RMSE_TOL),
-                             "against": out["cpu_baseline"]["kind"], "sample": f"{W}x{H}, {args.cpu_spp} spp, depth {p['depth']}: the frame of the cpu_baseline leg"}
-            if not e < RMSE_TOL:
-                status = 3
+    if not args.no_cpu_baseline:
+        cb, ref_frame = (None, None)
+        if rank == 0:
+            cb, ref_frame = cpu_baseline(scene, p, args)
+        have = [cb is not None]
+        if world > 1:
+            dist.broadcast_object_list(have, src=0)
+        if have[0]:
+            pp = dict(p, spp=args.cpu_spp)
+            if world == 1:
+                img, _ = dscene.render(pp, flags=args.flags)
+            else:
+                fb2 = torch.zeros_like(fb)
+                dscene.render_into(fb2, pp, rank=rank, world_size=world, flags=args.flags, stream=stream)
+                merge_frame(fb2)
+                torch.cuda.synchronize()
+                img = fb2.cpu().numpy()
+            if rank == 0:
+                entry, ref_order = cb
+                if world == 1:
+                    out["cpu_baseline"] = entry
+                e = float(np.sqrt(np.mean((np.nan_to_num(img[..., :3]).astype(np.float64) - np.nan_to_num(ref_frame[..., :3])) ** 2)))
+                same = float(np.mean(np.all(img.view(np.uint32) == ref_frame.view(np.uint32), axis=-1)))
+                out["parity"] = {"rmse": e, "identical_pixel_fraction": round(same, 6), "tolerance": RMSE_TOL, "ok": bool(e < RMSE_TOL),
+                                 "against": entry["kind"], "sample": f"{W}x{H}, {args.cpu_spp} spp, depth {p['depth']}: the frame of the CPU leg"
+                                 + ("" if world == 1 else f", GPU frame merged from {world} ranks")}
+                if not e < RMSE_TOL:
+                    status = 3
 
-    # ---- rooflines of the three large kernels -------------------------------------------------------
-    if not args.no_roofline and world == 1 and not (args.flags & 5):
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    # ---- rooflines of the three large kernels (rank 0's share of the frame at N > 1) -----------------
+    if not args.no_roofline and not (args.flags & 5):
         # exact test counters from the instrumented twin library (one untimed pass; the workload is
         # deterministic so the counts are those of every timed pass)
         dscene.close()           # hand its batch buffers back: the counting pass is one batch too, launch for launch
         ds2 = api.DeviceScene(scene, device=local_rank, instrumented=True)
-        _, c = ds2.render(p, flags=args.flags)
+        _, c = ds2.render(p, rank=rank, world_size=world, flags=args.flags)
         ds2.close()
         # SURVEY §8(d) per-unit figures. B_traversal = 32 N_box + 52 N_tri + 48 per ray; B_shade = 116 per hit + 64 per
         # entry + 4 C per texture tap. The traversal figures are taken twice: from the kernel's own tallies (they include
@@ -364,6 +503,8 @@ def main():
             if tr and t > 0:
                 e["traffic_GBps"] = round(e["traffic"] / t * 1e-9, 1)
                 e["traffic_frac_of_hbm_peak"] = round(e["traffic"] / t * 1e-9 / HBM_PEAK_GBPS, 4)
+            if world > 1:
+                e["share"] = f"rank 0 of {world}"
         dominant = max(entries, key=lambda e: e["avg_launch_ms"] * e["launches_per_step"])
         out["roofline"] = dominant
         out["rooflines"] = entries
@@ -374,6 +515,7 @@ def main():
         out["counts_per_step"] = {k: c[k] for k in ("traversals", "box_tests", "tri_tests", "shaded_hits")}
     print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     return status
 

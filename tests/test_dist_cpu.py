@@ -52,6 +52,35 @@ def test_two_rank_merge_gloo():
     assert res[0] and res[1]
 
 
+def test_bench_dry_launch_spawns_the_ranks_it_was_asked_for():
+    """`python bench.py --gpus 2 --dry-launch` — the command form the driver uses, without torchrun around it — starts two
+    gloo ranks itself, each holds the blocks the library's partition gives it of a synthetic frame, the reduce gives the
+    full frame back on rank 0, and the line says n_gpus = 2 (--gpus was parsed and never read)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["dry_launch"] and line["n_gpus"] == 2 and line["merged_equals_full_frame"]
+    assert len(line["pixels_per_rank"]) == 2 and sum(line["pixels_per_rank"]) == line["frame"][0] * line["frame"][1]
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """No GPU here: `--gpus 2` must fail loudly (exit 2) instead of timing one device, and a torchrun world that
+    differs from --gpus is refused as well."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 2 and "refusing" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
+
+
 def test_bench_cpu_baseline_leg_runs_on_a_small_case():
     """bench.py's cpu_baseline leg (the compiled reference, or the oracle, timed on the host cores) on a 32x32 case,
     with the library-only keys the bench carries in its parameter dict: the timing entry, the frame the parity gate

@@ -254,3 +254,84 @@ def test_rccl_calls_of_the_merge_run_on_this_box(api):
     L.yart_hip_multi_rccl_selftest.argtypes = [ctypes.c_int, ctypes.c_uint32]
     rc = L.yart_hip_multi_rccl_selftest(0, 1 << 20)
     assert rc == 0, (rc, L.yart_hip_last_error())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Two and more GPUs: these tests enable themselves the moment the box shows >= 2 devices (a one-GPU box skips them;
+# everything around the transport runs there through the one-device rehearsals above).
+# ---------------------------------------------------------------------------------------------------------------
+def _n_devices():
+    try:
+        from yart_amd import api as _api
+        return int(_api.lib().yart_hip_device_count())
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs >= 2 HIP devices (RCCL branch of multi_device.inc)")
+def test_multi_device_rccl_branch_equals_single_device(api):
+    """MultiDeviceScene over DISTINCT devices: the grouped ncclSend / ncclRecv merge (multi_device.inc, `distinct`) must
+    give the single-device frame bit for bit — whole tiles, 16-pixel blocks, several waves, every visible device."""
+    from yart_amd import scenes
+    n = min(_n_devices(), 8)
+    s, p = scenes.sponza_class(240, 136, 8, 6, tex=128, sky=128)
+    single = api.DeviceScene(s, device=0)
+    want, st1 = single.render(p)
+    for devs in ([0, 1], list(range(n))):
+        multi = api.MultiDeviceScene(s, devs)
+        got, st = multi.render(p)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), devs
+        assert st["samples"] == st1["samples"] and st["rays"] == st1["rays"]
+        q = dict(p, shard_tile=16, first_wave=2, max_wave=4)
+        want2, _ = single.render(q)
+        got2, _ = multi.render(q)
+        assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32)), devs
+        got3, _ = multi.render(q)                    # a second render re-uses the communicators
+        assert np.array_equal(got3.view(np.uint32), want2.view(np.uint32)), devs
+        multi.close()
+    single.close()
+
+
+def _nccl_rank(rank, world, port, q):
+    import os as _os
+    import sys as _sys
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from tests.conftest import ROOT
+    _sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from yart_amd import api as _api, dist as yd, scenes
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    s, p = scenes.sponza_class(240, 136, 8, 6, tex=128, sky=128)
+    p = dict(p, shard_tile=16)
+    ds = _api.DeviceScene(s, device=rank)
+    fb = torch.zeros((136, 240, 4), dtype=torch.float32, device="cuda")
+    yd.render_sharded(ds, p, fb, rank, world, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ok = True
+    if rank == 0:
+        want, _ = ds.render(p)
+        ok = bool(np.array_equal(fb.cpu().numpy().view(np.uint32), want.view(np.uint32)))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+    ds.close()
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs >= 2 HIP devices (process-per-GPU RCCL reduce)")
+def test_two_process_render_sharded_nccl(api):
+    """yart_amd.dist.render_sharded with backend nccl (= RCCL), one process per GPU: rank 0's merged frame equals the
+    frame one device renders alone, bit for bit (what bench.py --gpus N times)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_nccl_rank, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert res[0] and res[1]

@@ -1012,8 +1012,9 @@ int yart_hip_multi_rccl_selftest(int device, uint32_t n_floats) {
     if (dev < 0) throw HipError("no usable HIP device (libyart_hip has no CPU fallback)");
     HIP_CHECK(hipSetDevice(dev));
     // the calls of mergeSlabs on a one-rank communicator: the rank sends a slab to itself (matching send / recv in one group)
+    const RcclApi& R = rccl();
     ncclComm_t comm = nullptr;
-    RCCL_CHECK(ncclCommInitAll(&comm, 1, &dev));
+    RCCL_CHECK(R.CommInitAll(&comm, 1, &dev));
     hipStream_t st = nullptr;
     DevBuf<float> a, b;
     std::vector<float> h(n_floats), back(n_floats, 0.0f);
@@ -1022,19 +1023,21 @@ int yart_hip_multi_rccl_selftest(int device, uint32_t n_floats) {
       HIP_CHECK(hipStreamCreate(&st));
       a.upload(h); b.ensure(n_floats);
       HIP_CHECK(hipMemsetAsync(b.p, 0, size_t(n_floats) * 4, st));
-      RCCL_CHECK(ncclGroupStart());
-      RCCL_CHECK(ncclSend(a.p, n_floats, ncclFloat, 0, comm, st));
-      RCCL_CHECK(ncclRecv(b.p, n_floats, ncclFloat, 0, comm, st));
-      RCCL_CHECK(ncclGroupEnd());
+      RCCL_CHECK(R.GroupStart());
+      ncclResult_t e = R.Send(a.p, n_floats, ncclFloat, 0, comm, st);
+      if (e == ncclSuccess) e = R.Recv(b.p, n_floats, ncclFloat, 0, comm, st);
+      const ncclResult_t ge = R.GroupEnd();                 // closed whatever the calls inside returned
+      RCCL_CHECK(e);
+      RCCL_CHECK(ge);
       HIP_CHECK(hipStreamSynchronize(st));
       HIP_CHECK(hipMemcpy(back.data(), b.p, size_t(n_floats) * 4, hipMemcpyDeviceToHost));
     } catch (...) {
       if (st) (void)hipStreamDestroy(st);
-      (void)ncclCommDestroy(comm);
+      (void)R.CommDestroy(comm);
       throw;
     }
     (void)hipStreamDestroy(st);
-    RCCL_CHECK(ncclCommDestroy(comm));
+    RCCL_CHECK(R.CommDestroy(comm));
     if (std::memcmp(h.data(), back.data(), size_t(n_floats) * 4) != 0) throw RcclFailure("rccl selftest: the received slab differs from the sent one");
   });
 }

@@ -148,10 +148,6 @@ typedef struct YartRenderParams {
                                        since round 2 (measured: shade stage -8.4 % on the McLaren-class scene, -0.5 % on the
                                        Sponza-class one; round 1 bucketed by material index and lost 5 % there) */
 #define YART_FLAG_NO_SHADE_SORT 64u /* shade the queue entries in queue order */
-#define YART_FLAG_SAMPLER_ROWS 1024u  /* per-render sampler tables also hold the permutation rows of the low sample digits (otherwise hashed per
-                                       draw). Measured on C3: the 33 ms build and the row gathers cost more than the hashes (shade kernel
-                                       331 -> 364 ms); the reading code is compiled out of the default build (-DYART_SAMPLER_ROWS=1 brings it back; the
-                                       flag is ignored otherwise) */
 #define YART_FLAG_WIDE_BVH 128u     /* lean traversal kernels walk a 4-wide re-layout of the reference's binary tree (same boxes,
                                        same triangle tests; children nearest-first over four). Frames equal the binary walk's bit for bit: rays
                                        that meet an alpha-tested triangle or two triangles at exactly the same t go to the general

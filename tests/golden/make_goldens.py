@@ -36,6 +36,10 @@ CASES = {
                  [(48, 32), (5, 5), (75, 45), (20, 50), (50, 15), (48, 50), (90, 60)]),
     # two waves (8 + 8 spp) to pin the wave blend and sampleOffset handling
     "cornell_waves": (lambda: _waves(), [(32, 32), (10, 50)]),
+    # the reference's other environment preset: UniformInfiniteLight (light.cpp:83-131) + the box's area light
+    "uniform_sky": (lambda: scenes.uniform_sky(64, 64, 16, 4), [(32, 32), (5, 60)]),
+    # two infinite lights at once (image + uniform): the miss loop and pInfinite with nInfinite = 2
+    "two_skies": (lambda: scenes.two_skies(48, 32, 8, 5), [(24, 16), (40, 5)]),
 }
 
 

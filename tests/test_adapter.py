@@ -15,6 +15,13 @@ EXE = os.path.join(ROOT, "oracle", "_ref", "yart_ref_hip")
 needs_exe = pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/yart_ref_hip not built (needs the reference sources)")
 
 
+@pytest.fixture(scope="module")
+def adapter_exe():
+    """On a GPU run the adapter binary (built here against the reference's headers, pushed prebuilt) must be there: fail, not skip."""
+    from tests.conftest import _checker
+    return _checker(EXE, "the reference-side adapter binary")
+
+
 def run(tmp_path, params, look="-"):
     out = os.path.join(tmp_path, "a.f32")
     r = subprocess.run([EXE, os.path.join(G, "gallery.glb"), os.path.join(G, "env_rle.hdr"), params, out, look],
@@ -31,9 +38,8 @@ def test_adapter_fails_loudly_without_a_device(built, tmp_path):
     assert r.returncode == 3 and "no usable HIP device" in r.stderr
 
 
-@needs_exe
 @pytest.mark.gpu
-def test_adapter_render_equals_reference(tmp_path):
+def test_adapter_render_equals_reference(adapter_exe, tmp_path):
     p = load_params(os.path.join(G, "gallery.txt"))
     w, h = p["size"]
     r, out = run(tmp_path, os.path.join(G, "gallery.txt"))
@@ -51,9 +57,8 @@ def test_adapter_render_equals_reference(tmp_path):
     assert same.all()
 
 
-@needs_exe
 @pytest.mark.gpu
-def test_adapter_waves_follow_the_reference_schedule(tmp_path):
+def test_adapter_waves_follow_the_reference_schedule(adapter_exe, tmp_path):
     """first_wave 2, max_wave 8 over 16 spp: waves of 2, 4, 8, 2 (tile-renderer.hpp:284-289), blended as one
     uninterrupted render of the library blends them."""
     from yart_amd import api, scenes
@@ -72,9 +77,8 @@ def test_adapter_waves_follow_the_reference_schedule(tmp_path):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@needs_exe
 @pytest.mark.gpu
-def test_adapter_tile_callbacks_and_multi_device(tmp_path):
+def test_adapter_tile_callbacks_and_multi_device(adapter_exe, tmp_path):
     """HipRenderer with onRenderTileComplete set (yart_hip_render_tiles: Renderer::TileData per finished tile, the
     renderer's buffer holding the tonemapped tile) and with a MultiDeviceScene (yart_hip_multi_render; GPU 0 named
     twice on a one-GPU box): both give the frame of the plain adapter render."""

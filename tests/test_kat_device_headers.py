@@ -10,7 +10,7 @@ import pytest
 from tests import katlib
 from tests.conftest import GOLDEN
 
-CASES = ["cornell", "material", "cornell_waves"]
+CASES = ["cornell", "material", "cornell_waves", "uniform_sky", "two_skies"]
 # ggxGlassEavg exists in the reference (luts.hpp:167-191) but nothing on the path calls it
 UNUSED = {"ggxGlassEavg"}
 

@@ -39,7 +39,6 @@ FLAG_NO_REFILL = 16
 FLAG_NO_COMPACTION = 32
 FLAG_NO_SHADE_SORT = 64
 FLAG_WIDE_BVH = 128
-FLAG_SAMPLER_ROWS = 1024
 
 
 class YartError(RuntimeError):
@@ -579,11 +578,15 @@ class HipTileRenderer:
                                                         (time.perf_counter() - t0) * 1e3, {}), info)
             return self._abort
         if self.on_render_tile_complete:
+            display = [None]               # ONE persistent display buffer per render (integration/hip-renderer.hpp::expose does the same)
+
             def on_tile(frame, tile):
                 x, y, w, h = tile["x"], tile["y"], tile["width"], tile["height"]
                 view = frame
-                if self.tonemapper:        # tile-renderer.hpp:234-239 maps the finished tile only
-                    view = frame.copy()
+                if self.tonemapper:        # tile-renderer.hpp:234-239 maps the finished tile only, into the buffer it exposes
+                    if display[0] is None:
+                        display[0] = np.zeros_like(frame)
+                    view = display[0]
                     view[y:y + h, x:x + w] = tonemap(np.ascontiguousarray(frame[y:y + h, x:x + w]), self.tonemapper)[0]
                 self.on_render_tile_complete(RenderData(view, tile["samples_taken"] - tile["wave_samples"], self.samples, 0,
                                                         (time.perf_counter() - t0) * 1e3, {}), tile)

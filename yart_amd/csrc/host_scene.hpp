@@ -268,6 +268,10 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
     im.meshes.push_back(md);
     im.bvhIndices.push_back(std::move(b.indices));
   }
+  // The lean inner step lets lanes that only pop read nodes[1], nodes[2] of their mesh unconditionally (the root's children;
+  // the values are discarded). For a mesh whose tree is a single leaf those slots lie behind the mesh — for the LAST mesh behind
+  // the array: two zero records keep that read inside the allocation.
+  im.bvhNodes.push_back(BvhNode{}); im.bvhNodes.push_back(BvhNode{});
 
   // ---- scene graph (scene.hpp:11-64): pre-order with skip links, children-inclusive bounds
   const uint32_t nn = d.n_nodes;
@@ -370,7 +374,13 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
     std::vector<uint32_t> ids;
     for (uint32_t i = 0; i < nn; i++) if (im.nodes[i].mesh >= 0) ids.push_back(i);
     if (!ids.empty()) {
-      auto centre = [&](uint32_t n, int c) { return 0.5f * ((&im.nodeWorld[2 * n].x)[c] + (&im.nodeWorld[2 * n + 1].x)[c]); };
+      // (a node whose padded world box is not finite — lo = -inf, hi = +inf — would give a NaN centre, and a comparator over
+      // NaNs is not a strict weak ordering: undefined behaviour in std::nth_element. Such centres count as 0; the hierarchy
+      // only filters, any split is valid.)
+      auto centre = [&](uint32_t n, int c) {
+        const float v = 0.5f * ((&im.nodeWorld[2 * n].x)[c] + (&im.nodeWorld[2 * n + 1].x)[c]);
+        return std::isfinite(v) ? v : 0.0f;
+      };
       im.tlas.resize(2 * ids.size() - 1);
       uint32_t used = 1;
       std::function<void(uint32_t, uint32_t, uint32_t)> build = [&](uint32_t at, uint32_t lo, uint32_t hi) {

@@ -20,30 +20,14 @@ namespace yart_hip {
 // plus hashDim(d) for d <= dims, and byte-wise XOR tables of the Sobol' dimension-1 matrix.
 // A draw then costs 2 table reads + the remaining (spp-dependent) low digits instead of
 // nBase4Digits 64-bit hash evaluations. Dimensions >= dims fall back to the direct evaluation.
-// 1: the per-draw code can read the rows of the low sample digits (YART_FLAG_SAMPLER_ROWS); 0: compiled out — the default,
-// because the mere presence of that path costs the shade kernel 12 ms per C3 frame (442 -> 454 ms shade stage) with the flag off
-#ifndef YART_SAMPLER_ROWS
-#if defined(__HIPCC__)
-#define YART_SAMPLER_ROWS 0
-#else
-#define YART_SAMPLER_ROWS 1      // host builds (tests/hostsim selftest) keep it: table form == direct form, every budget
-#endif
-#endif
+// (Tables for the low digits as well — 80 B instead of 8 B per dimension and pixel — were measured in round 2 and
+// lose: the gathers cost more than the hashes, profiles/r2_sampler_rows_kernel_stats.txt; removed.)
 struct SamplerTables {
   const uint64_t* entries = nullptr;   // [dims][stride]
   const uint64_t* hash = nullptr;      // [dims + 3]
   const uint32_t* sobol1 = nullptr;    // [8][256]: XOR of the matrix columns selected by byte b of the index
   uint32_t dims = 0, stride = 0;
-  // Permutation rows of the sample digits BELOW the two the entry holds (round 2). Those digits were hashed per draw
-  // (one 64-bit mixBits each, ~50 instructions; two of them per draw at 256 spp: a quarter of the shade kernel). Level k
-  // stands for digit firstPixelDigit - 3 - k; its row depends on the pixel, the dimension and the 4 + 2k sample bits above
-  // the digit, so it has 16 * 4^k rows of one byte, at samplerRowOffset(k) inside the rowBytes of one (dimension, pixel).
-  // lastBit: the xor bit of an odd log2spp (sampler.hpp:168-171) for each of the 2^(log2spp - 1) sample prefixes, as bits
-  // after the rows.
-  const uint8_t* rows = nullptr;       // [dims][stride][rowBytes]
-  uint32_t rowBytes = 0, rowLevels = 0, lastBit = 0, lastBitOffset = 0;
 };
-YART_HD uint32_t samplerRowOffset(uint32_t level) { return (16u * ((1u << (2u * level)) - 1u)) / 3u; }   // 0, 16, 80, 336
 
 struct SamplerConfig {
   uint32_t log2spp;       // log2Int(float(spp)), math_base.hpp:156-160
@@ -177,38 +161,6 @@ YART_HD uint64_t getSampleIndexDirect(const Sampler& s, const SamplerConfig& c) 
 // lie entirely in the pixel bits (a digit never straddles: digitShift has the parity of log2spp).
 YART_HD int samplerFirstPixelDigit(const SamplerConfig& c) { return int((c.log2spp + 1u) / 2u); }
 
-// How many digit levels (and whether the last bit) fit `budget` bytes per (dimension, pixel); fills the layout fields of t.
-YART_HD void samplerRowLayout(const SamplerConfig& c, uint32_t budget, SamplerTables& t) {
-  const int lastDigit = int(c.log2spp & 1u);
-  const int remaining = samplerFirstPixelDigit(c) - 2 - lastDigit;      // sample digits below the entry's two
-  uint32_t levels = 0;
-  while (int(levels) < remaining && levels < 4u && samplerRowOffset(levels + 1u) <= budget) levels++;
-  uint32_t bytes = samplerRowOffset(levels);
-  t.rowLevels = levels; t.lastBit = 0; t.lastBitOffset = bytes;
-  if (lastDigit && int(levels) == (remaining > 0 ? remaining : 0) && c.log2spp >= 1u && c.log2spp <= 12u) {
-    const uint32_t bitBytes = ((1u << (c.log2spp - 1u)) + 7u) / 8u;
-    if (bytes + bitBytes <= budget) { t.lastBit = 1; bytes += bitBytes; }
-  }
-  t.rowBytes = (bytes + 3u) & ~3u;
-}
-// byte `b` of the rows of (pixelMorton, dim): what samplerRowLayout laid out
-YART_HD uint8_t samplerRowByte(const SamplerConfig& c, const SamplerTables& t, uint64_t pixelMorton, uint32_t dim, uint32_t b) {
-  const int lastDigit = int(c.log2spp & 1u);
-  const uint64_t dimMix = uint64_t(0x55555555u * dim);
-  if (b < t.lastBitOffset) {
-    uint32_t level = 0;
-    while (b >= samplerRowOffset(level + 1u)) level++;
-    const uint32_t prefix = b - samplerRowOffset(level), bits = 4u + 2u * level;
-    return uint8_t(permutationRowFor((pixelMorton << bits) | prefix, dimMix));
-  }
-  if (!t.lastBit || !lastDigit) return 0;
-  const uint32_t first = (b - t.lastBitOffset) * 8u, n = 1u << (c.log2spp - 1u);
-  uint32_t v = 0;
-  for (uint32_t k = 0; k < 8u && first + k < n; k++)
-    v |= uint32_t(mixBits(((pixelMorton << (c.log2spp - 1u)) | (first + k)) ^ dimMix) & 1ull) << k;
-  return uint8_t(v);
-}
-
 YART_HD uint64_t samplerTableEntry(const SamplerConfig& c, uint64_t pixelMorton, uint32_t dim) {
   const int lastDigit = int(c.log2spp & 1u);
   const uint64_t dimMix = uint64_t(0x55555555u * dim);
@@ -241,35 +193,17 @@ YART_HD uint64_t getSampleIndex(const Sampler& s, const SamplerConfig& c) {
       const uint32_t shift2 = shift - 2u;
       const uint32_t digit = uint32_t(s.morton >> shift2) & 3u;
       index |= uint64_t((uint32_t(e >> (32u + 8u * top)) >> (2u * digit)) & 3u) << shift2;
-#if defined(YART_EXP_SKIP_LOW_DIGITS)     // timing experiment only (wrong samples): what the directly hashed digits cost
-      i = lastDigit - 1;
-#endif
-#if YART_SAMPLER_ROWS
-      const uint8_t* rows = c.tab.rows ? c.tab.rows + (size_t(s.dim) * c.tab.stride + s.pix) * c.tab.rowBytes : nullptr;
-#else
-      const uint8_t* rows = nullptr;
-#endif
-      uint32_t level = 0;
-      for (--i; i >= lastDigit; i--, level++) {                 // remaining digits: from the row table, else hashed
+      for (--i; i >= lastDigit; i--) {                          // remaining (spp-dependent) digits: hashed per draw
         const uint32_t digitShift = uint32_t(2 * i - lastDigit);
         const uint32_t dg = uint32_t(s.morton >> digitShift) & 3u;
-        uint32_t row;
-        if (rows != nullptr && level < c.tab.rowLevels) {
-          const uint32_t prefix = uint32_t(s.morton >> (digitShift + 2u)) & ((1u << (4u + 2u * level)) - 1u);
-          row = rows[samplerRowOffset(level) + prefix];
-        } else row = permutationRowFor(s.morton >> (digitShift + 2), dimMix);
+        const uint32_t row = permutationRowFor(s.morton >> (digitShift + 2), dimMix);
         index |= uint64_t((row >> (2u * dg)) & 3u) << digitShift;
       }
     }
   }
   if (lastDigit) {
     const uint32_t digit = uint32_t(s.morton & 1ull);
-    uint32_t mix;
-    if (YART_SAMPLER_ROWS && c.tab.rows != nullptr && c.tab.lastBit) {
-      const uint32_t prefix = uint32_t(s.morton >> 1) & ((1u << (c.log2spp - 1u)) - 1u);
-      const uint8_t* rows = c.tab.rows + (size_t(s.dim) * c.tab.stride + s.pix) * c.tab.rowBytes;
-      mix = (uint32_t(rows[c.tab.lastBitOffset + (prefix >> 3)]) >> (prefix & 7u)) & 1u;
-    } else mix = uint32_t(mixBits((s.morton >> 1) ^ dimMix) & 1ull);
+    const uint32_t mix = uint32_t(mixBits((s.morton >> 1) ^ dimMix) & 1ull);
     index |= uint64_t(digit ^ mix);
   }
   return index;

@@ -34,26 +34,6 @@ constexpr uint32_t kLeanRefill = YART_LEAN_REFILL;      // refill when at least 
 #endif
 constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;   // leave the inner loop when fewer lanes than this still step
 
-// inner loop of part (C): 1 = trace_lean_bvh.inc (round 1), 2 = trace_lean_bvh2.inc (straight-line step, lane state in VGPRs)
-#ifndef YART_LEAN_LOOP
-#define YART_LEAN_LOOP 2
-#endif
-
-// lean kernels evaluate an alpha-tested candidate's texture alpha themselves and hand the ray over only where it is not opaque
-#ifndef YART_LEAN_ALPHA_PEEK
-#define YART_LEAN_ALPHA_PEEK 0
-#endif
-
-// inner step: node-pair loads and box tests in one predicated region (1) or unconditional with pop-only lanes reading the root pair (0)
-#ifndef YART_LEAN_MASKED_LOADS
-#define YART_LEAN_MASKED_LOADS 0
-#endif
-
-// lean shadow kernel without near / far ordering and with a fixed interval (trace_lean_bvh2.inc)
-#ifndef YART_SHADOW_ANYORDER
-#define YART_SHADOW_ANYORDER 0
-#endif
-
 struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general variant only (alpha tests)
 
 // Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)
@@ -61,23 +41,14 @@ struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general var
 // (wave-wide call). MODE without TRAV_FAST = the general walk (alpha tests inline, no hand-over).
 template <bool NEE, int MODE, class Fetch, class Commit, class Retry>
 __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk, const uint32_t* queue,
-                                          uint32_t count, uint32_t* cursor, uint32_t nSegIn, Fetch fetch, Commit commit,
+                                          uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
                                           Retry retry, WfTally& tally) {
   constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
   Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
   f3 attenuation = mk3(1.0f);
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long laneLt = (1ull << lane) - 1ull;
-  // XCD-aware dequeue: workgroups are dealt round-robin to the 8 XCDs (an affinity, used for speed only), so
-  // the queue is cut into nSeg contiguous segments with one cursor each and a wave starts in the segment of
-  // its XCD — neighbouring queue entries (camera rays: neighbouring pixels) then share one XCD's L2 — and
-  // moves on to the other segments when its own is drained. cursor points to nSeg words.
-  const uint32_t nSeg = (nSegIn > 1u && gridDim.x % nSegIn == 0u) ? nSegIn : 1u;
-  const uint32_t wavesPerBlock = blockDim.x >> 6;
-  const uint32_t localWave = (blockIdx.x / nSeg) * wavesPerBlock + (threadIdx.x >> 6);
-  const uint32_t wavesPerSeg = (gridDim.x / nSeg) * wavesPerBlock;
-  const uint32_t segLen = (((count + nSeg - 1u) / nSeg) + 63u) & ~63u;
-  uint32_t seg = blockIdx.x % nSeg, segsTried = 0;
+  const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
   const float tMin = 0.001f;
   bool has = false, inMesh = false, exhausted = false, firstFill = true, pendingRetry = false;
   bool didHit = false, meshDidHit = false, rayIsWorld = false;
@@ -91,8 +62,6 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
   // MODE & TRAV_WIDE (trace_wide_bvh.inc): cursor into the mesh's 4-wide records, their base, the interval end on entering the mesh
   uint32_t wideCur = 0, wideBase = 0;
   float tEntry = 0.0f;
-  // YART_LEAN_LOOP == 3 (trace_lean_bvh3.inc): the leaf a lane has put aside, its entry distance, "the stack ran empty after it"
-  uint32_t pendLink = 0; float pendD = 0.0f; bool pendExhausted = false;
   // scene nodes this ray can reach at all: bit n survives if the padded world box of n and of all
   // its ancestors is hit within [0, tMax] (conservative, see traverseScene); used for scenes of fewer than 64 nodes (the all-ones mask marks a new ray)
   unsigned long long cand = 0;
@@ -110,26 +79,21 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
     const uint32_t nIdle = uint32_t(__popcll(idle));
     if (nIdle == 64u && exhausted) break;
     if (!exhausted && nIdle >= kLeanRefill) {
-      uint32_t base = 0, segEnd = 0;
+      uint32_t base;
       if (firstFill) {                                          // by wave index, no atomic
         firstFill = false;
-        base = seg * segLen + localWave * 64u;
-        segEnd = (seg + 1u) * segLen < count ? (seg + 1u) * segLen : count;
+        base = waveId * 64u;
+        if (nWaves * 64u >= count) exhausted = true;
       } else {
         const int leader = __ffsll((long long) idle) - 1;
-        for (;;) {                                              // wave-uniform
-          uint32_t c = 0;
-          if (int(lane) == leader) c = atomicAdd(cursor + seg, nIdle);
-          base = seg * segLen + wavesPerSeg * 64u + __shfl(c, leader);
-          segEnd = (seg + 1u) * segLen < count ? (seg + 1u) * segLen : count;
-          if (base < segEnd) break;
-          seg = seg + 1u == nSeg ? 0u : seg + 1u;               // this segment is drained: the next one
-          if (++segsTried >= nSeg) { exhausted = true; break; }
-        }
+        base = 0;
+        if (int(lane) == leader) base = atomicAdd(cursor, nIdle);
+        base = nWaves * 64u + __shfl(base, leader);
+        if (base + nIdle >= count) exhausted = true;           // wave-uniform
       }
       if (!has) {
         const uint32_t k = base + uint32_t(__popcll(idle & laneLt));
-        if (k < segEnd) {
+        if (k < count) {
           WF_PHASE(tally, 6);                                   // refills / rays fetched
           slot = queue[k];
           const LeanRay r = fetch(slot);
@@ -198,7 +162,6 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
-                  pendLink = 0; pendExhausted = false;
                   if (MODE & TRAV_WIDE) { wideCur = root.leftFirst & kLinkAlphaBit; wideBase = mesh.wideOffset; tEntry = hit.t; }
                 }
               }
@@ -212,17 +175,11 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
     if constexpr ((MODE & TRAV_WIDE) != 0) {
 #include "trace_wide_bvh.inc"
     } else {
-#if YART_LEAN_LOOP == 3
-#include "trace_lean_bvh3.inc"
-#elif YART_LEAN_LOOP == 2
 #include "trace_lean_bvh2.inc"
-#else
-#include "trace_lean_bvh.inc"
-#endif
     }
   }
 #undef LEAN_VISIT
-  (void)meshHasAlpha; (void)wideCur; (void)wideBase; (void)tEntry; (void)pendLink; (void)pendD; (void)pendExhausted;
+  (void)meshHasAlpha; (void)wideCur; (void)wideBase; (void)tEntry;
 #if defined(YART_COUNT_TRAVERSAL)
   tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
 #else

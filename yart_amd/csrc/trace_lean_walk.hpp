@@ -33,7 +33,7 @@ namespace yart_hip {
 // (wave-wide call). MODE without TRAV_FAST = the general walk (alpha tests inline, no hand-over).
 template <bool NEE, int MODE, class Fetch, class Commit, class Retry>
 __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk, const uint32_t* queue,
-                                          uint32_t count, uint32_t* cursor, uint32_t /*nSeg: single cursor here*/, Fetch fetch,
+                                          uint32_t count, uint32_t* cursor, Fetch fetch,
                                           Commit commit, Retry retry, WfTally& tally) {
   constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
   Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
@@ -54,8 +54,6 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
   // MODE & TRAV_WIDE (trace_wide_bvh.inc): cursor into the mesh's 4-wide records, their base, the interval end on entering the mesh
   uint32_t wideCur = 0, wideBase = 0;
   float tEntry = 0.0f;
-  // YART_LEAN_LOOP == 3 (trace_lean_bvh3.inc): the leaf a lane has put aside, its entry distance, "the stack ran empty after it"
-  uint32_t pendLink = 0; float pendD = 0.0f; bool pendExhausted = false;
 #if defined(YART_COUNT_TRAVERSAL)
   AlphaCtx actx; actx.sampler = nullptr;     // only its counters are used (YART_COUNT)
 #endif
@@ -148,7 +146,6 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
-                  pendLink = 0; pendExhausted = false;
                   if (MODE & TRAV_WIDE) { wideCur = root.leftFirst & kLinkAlphaBit; wideBase = mesh.wideOffset; tEntry = hit.t; }
                 }
               }
@@ -162,17 +159,11 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
     if constexpr ((MODE & TRAV_WIDE) != 0) {
 #include "trace_wide_bvh.inc"
     } else {
-#if YART_LEAN_LOOP == 3
-#include "trace_lean_bvh3.inc"
-#elif YART_LEAN_LOOP == 2
 #include "trace_lean_bvh2.inc"
-#else
-#include "trace_lean_bvh.inc"
-#endif
     }
   }
 #undef LEAN_VISIT
-  (void)meshHasAlpha; (void)wideCur; (void)wideBase; (void)tEntry; (void)pendLink; (void)pendD; (void)pendExhausted;
+  (void)meshHasAlpha; (void)wideCur; (void)wideBase; (void)tEntry;
 #if defined(YART_COUNT_TRAVERSAL)
   tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
 #else

@@ -25,10 +25,6 @@
 namespace yart_hip {
 
 constexpr uint32_t kRefStackDepth = 64;     // ray-integrator.cpp:92-93
-#ifndef YART_PK_BOX
-#define YART_PK_BOX 0
-#endif
-
 struct RayO {                // core/ray.hpp:9-30 (object-space ray with slab precomputations)
   f3 o, d, idir, odir;
   uint32_t sx, sy, sz;
@@ -60,44 +56,13 @@ YART_HD bool testBox(const RayO& r, float tIntMin, float tIntMax, const float* b
   return t1 >= t0;
 }
 
-// Both children of an inner node at once (same operations per box as testBox). Issuing the six
-// multiply / add pairs of the two boxes as packed fp32 (v_pk_mul_f32 / v_pk_add_f32) was measured: it
-// saves 12 VALU per step but raises the register count past an occupancy step, and was slower.
-#if defined(__HIP_DEVICE_COMPILE__) && YART_PK_BOX
-// Packed form: the x / y / z slab products of the two boxes side by side in v_pk_mul_f32 / v_pk_add_f32 (two IEEE
-// binary32 operations per instruction, each rounded like the scalar one; -ffp-contract=off keeps them unfused).
-typedef float box_v2 __attribute__((ext_vector_type(2)));
-YART_HD void testBox2(const RayO& r, float tIntMin, float tIntMax, const BvhNode& c1, const BvhNode& c2,
-                      bool& hit1, bool& hit2, float& d1, float& d2) {
-  box_v2 lo[3], hi[3];
-  const uint32_t sg[3] = {r.sx, r.sy, r.sz};
-  for (int a = 0; a < 3; a++) {
-    lo[a].x = sg[a] ? c1.bmax[a] : c1.bmin[a]; hi[a].x = sg[a] ? c1.bmin[a] : c1.bmax[a];
-    lo[a].y = sg[a] ? c2.bmax[a] : c2.bmin[a]; hi[a].y = sg[a] ? c2.bmin[a] : c2.bmax[a];
-  }
-  const float id[3] = {r.idir.x, r.idir.y, r.idir.z}, od[3] = {r.odir.x, r.odir.y, r.odir.z};
-  box_v2 tmn[3], tmx[3];
-  for (int a = 0; a < 3; a++) {
-    const box_v2 i2 = {id[a], id[a]}, o2 = {od[a], od[a]};
-    tmn[a] = lo[a] * i2 + o2;
-    tmx[a] = hi[a] * i2 + o2;
-  }
-  float t0 = tIntMin, t1 = tIntMax;
-  t0 = fmaxf(tmn[0].x, t0); t0 = fmaxf(tmn[1].x, t0); t0 = fmaxf(tmn[2].x, t0);
-  t1 = fminf(tmx[0].x, t1); t1 = fminf(tmx[1].x, t1); t1 = fminf(tmx[2].x, t1);
-  d1 = t0; hit1 = t1 >= t0;
-  t0 = tIntMin; t1 = tIntMax;
-  t0 = fmaxf(tmn[0].y, t0); t0 = fmaxf(tmn[1].y, t0); t0 = fmaxf(tmn[2].y, t0);
-  t1 = fminf(tmx[0].y, t1); t1 = fminf(tmx[1].y, t1); t1 = fminf(tmx[2].y, t1);
-  d2 = t0; hit2 = t1 >= t0;
-}
-#else
+// Both children of an inner node at once (same operations per box as testBox). (Packed fp32 for the six multiply /
+// add pairs was measured: 12 VALU fewer per step, but past an occupancy step in registers and slower)
 YART_HD void testBox2(const RayO& r, float tIntMin, float tIntMax, const BvhNode& c1, const BvhNode& c2,
                       bool& hit1, bool& hit2, float& d1, float& d2) {
   hit1 = testBox(r, tIntMin, tIntMax, c1.bmin, c1.bmax, d1);
   hit2 = testBox(r, tIntMin, tIntMax, c2.bmin, c2.bmax, d2);
 }
-#endif
 
 // Lane-private traversal stack: entry k of this lane is lds[k * ldsStride] for
 // k < ldsDepth, spill[(k - ldsDepth) * spillStride] beyond.

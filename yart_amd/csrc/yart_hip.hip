@@ -292,7 +292,7 @@ struct YartScene {
   DevBuf<uint32_t> wfTailMap[2];
   DevBuf<WfDyn> wfDyn;
   DevBuf<uint32_t> qA, qB, qS, qR, wfCounters; // wavefront queues
-  DevBuf<uint64_t> smpEntries, smpHash; DevBuf<uint32_t> smpSobol1, smpRows;   // SamplerTables of the current render
+  DevBuf<uint64_t> smpEntries, smpHash; DevBuf<uint32_t> smpSobol1;   // SamplerTables of the current render
   std::vector<uint32_t> pixelsHost;
   struct TileRec { uint32_t x, y, w, h, start, count; };     // a pixel block of this rank: its rectangle and its range of pixelsHost
   std::vector<TileRec> tiles;
@@ -556,7 +556,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   for (auto& b : s.wf) held += uint64_t(b.n) * 16;
   for (auto& t : s.wfTail) for (auto& b : t) held += uint64_t(b.n) * 16;
   held += (uint64_t(s.wfTailMap[0].n) + s.wfTailMap[1].n) * 4;
-  held += uint64_t(s.smpRows.n) * 4 + uint64_t(s.smpEntries.n) * 8;      // the sampler tables of the previous render stay allocated
+  held += uint64_t(s.smpEntries.n) * 8;      // the sampler tables of the previous render stay allocated
   // with compaction: two tail states of 1/2 and 1/4 of the batch (9 x 16 B + a slot map word each) = 111 B per path
   const bool compact = !mega && !(p.flags & YART_FLAG_NO_COMPACTION);
   const uint64_t perPath = mega ? 12 : compact ? 283 : 172;
@@ -595,15 +595,6 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     SamplerTabArgs ta{};
     ta.cfg = rc.sampler; ta.pixels = s.pixels.p; ta.nPixels = nPix; ta.dims = dims;
     ta.entries = s.smpEntries.p; ta.hash = s.smpHash.p; ta.sobol1 = s.smpSobol1.p;
-    // rows of the sample digits below the entry's two: as many levels as 1/16 of the device memory holds for these dimensions and pixels
-    if ((effFlags & YART_FLAG_SAMPLER_ROWS) && YART_SAMPLER_ROWS) {
-      const uint64_t budget = uint64_t(totalB) / 16u / (uint64_t(dims) * nPix);
-      samplerRowLayout(rc.sampler, uint32_t(std::min<uint64_t>(budget, 4096u)), ta.cfg.tab);
-      if (ta.cfg.tab.rowBytes != 0u) {
-        s.smpRows.ensure(size_t(dims) * nPix * (ta.cfg.tab.rowBytes / 4u));
-        ta.rows = s.smpRows.p;
-      }
-    }
     ta.matrix52 = reinterpret_cast<const uint32_t*>(s.dev.lut + LutDev::sobol);
     tShade.begin(stream);
     hipLaunchKernelGGL(k_sampler_tables, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, ta);
@@ -611,11 +602,6 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     tShade.end(stream);
     rcw.sampler.tab.entries = s.smpEntries.p; rcw.sampler.tab.hash = s.smpHash.p; rcw.sampler.tab.sobol1 = s.smpSobol1.p;
     rcw.sampler.tab.dims = dims; rcw.sampler.tab.stride = nPix;
-    if (ta.rows != nullptr) {
-      rcw.sampler.tab.rows = reinterpret_cast<const uint8_t*>(s.smpRows.p);
-      rcw.sampler.tab.rowBytes = ta.cfg.tab.rowBytes; rcw.sampler.tab.rowLevels = ta.cfg.tab.rowLevels;
-      rcw.sampler.tab.lastBit = ta.cfg.tab.lastBit; rcw.sampler.tab.lastBitOffset = ta.cfg.tab.lastBitOffset;
-    }
   }
 
   // wave schedule of tile-renderer.hpp:121-124, 284-289

@@ -19,7 +19,7 @@ import math
 
 import numpy as np
 
-from .yscn import (LIGHT_IMAGE_INF, TEX_LINEAR, TEX_NONCOLOR, TEX_SRGB, Light, Material, Mesh,
+from .yscn import (LIGHT_IMAGE_INF, LIGHT_UNIFORM_INF, TEX_LINEAR, TEX_NONCOLOR, TEX_SRGB, Light, Material, Mesh,
                    Scene, Texture, trs)
 
 
@@ -250,6 +250,23 @@ def cornell(width=256, height=256, spp=16, depth=4):
     p = dict(size=(width, height), spp=spp, depth=depth, focal=35.0, fnumber=0.0,
              eye=(0.0, 5.0, 15.0), target=(0.0, 5.0, 0.0), up=(0.0, 1.0, 0.0), exposure=0.0,
              background=(0.0, 0.0, 0.0))
+    return s, p
+
+
+def uniform_sky(width=64, height=64, spp=16, depth=4, emission=(0.6, 0.7, 1.0)):
+    """The Cornell box (open towards the camera) under the reference's alternative environment preset, a
+    UniformInfiniteLight (reference main.cpp:86, core/light.cpp:83-131): escaping rays pick up its emission, and the
+    power light sampler spends half of its NEE choices on a light whose sample() returns nothing."""
+    s, p = cornell(width, height, spp, depth)
+    s.lights.append(Light(LIGHT_UNIFORM_INF, radius=100.0, emission=tuple(emission)))
+    return s, p
+
+
+def two_skies(width=48, height=32, spp=8, depth=5, tex=32):
+    """material_test with a UniformInfiniteLight NEXT TO its image light: two infinite lights at once
+    (mis-integrator.cpp:27-43 loops over all of them on a miss; light-sampler.cpp:52-78 counts both in pInfinite)."""
+    s, p = material_test(width, height, spp, depth, tex=tex)
+    s.lights.append(Light(LIGHT_UNIFORM_INF, radius=100.0, emission=(0.3, 0.25, 0.2)))
     return s, p
 
 

@@ -9,6 +9,9 @@
 #include "scene_types.hpp"
 
 namespace yart_hip {
+#if YART_RELAXED_FP == 1
+#pragma clang fp contract(fast)     // measurement build only (tools/relaxed_fp_ab.py): fused multiply-adds in BSDF / light evaluation
+#endif
 
 // ---------------------------------------------------------------------------
 // Textures — repeat wrap, 4-tap bilinear, u8/255, gamma-2 decode for sRGB typed
@@ -248,8 +251,8 @@ YART_HD float ggxVmdf(const GGX& g, f3 w, f3 wm) {                      // bsdf.
 }
 YART_HD f2 sampleDiskUniform(f2 u) {                                    // math/sampling.hpp:40-45
   const float r = sqrtf(u.x);
-  const float theta = 2.0f * kPi * u.y;
-  return mk2(r * ycosf(theta), r * ysinf(theta));
+  const float theta = 2.0f * kPi * u.y;                       // u.y in [0, 1): theta in [0, 2 pi]
+  return mk2(r * ycosf2pi(theta), r * ysinf2pi(theta));
 }
 YART_HD f3 ggxSampleVisibleMicrofacet(const GGX& g, f3 w, f2 u) {       // bsdf.hpp:243-271
   f3 wh = normalized(mk3(g.ax * w.x, g.ay * w.y, w.z));
@@ -505,8 +508,8 @@ YART_HD float pdfGlossy(const float* lut, const MaterialDev& mt, f3 wo, f3 wi, c
 YART_HD f3 sampleCosineHemisphere(f2 u) {                               // math/sampling.hpp:30-38
   const float phi = u.x * 2.0f * kPi;
   const float sqrtr2 = sqrtf(u.y);
-  const float x = ycosf(phi) * sqrtr2;
-  const float y = ysinf(phi) * sqrtr2;
+  const float x = ycosf2pi(phi) * sqrtr2;                     // phi = 2 pi u.x in [0, 2 pi]
+  const float y = ysinf2pi(phi) * sqrtr2;
   const float z = sqrtf(1.0f - u.y);
   return mk3(x, y, z);
 }
@@ -717,4 +720,7 @@ YART_HD f3 bsdfNormal(const SceneDev& sc, const MaterialDev& mt, f3 n, f4 t, f2 
   return sn;
 }
 
+#if YART_RELAXED_FP == 1
+#pragma clang fp contract(off)
+#endif
 }  // namespace yart_hip

@@ -6,6 +6,9 @@
 #include "bsdf.hpp"
 
 namespace yart_hip {
+#if YART_RELAXED_FP == 1
+#pragma clang fp contract(fast)     // measurement build only (tools/relaxed_fp_ab.py): fused multiply-adds in BSDF / light evaluation
+#endif
 
 struct LightSample {         // core/light.hpp:10-15
   f3 Li, wi, p, n;
@@ -177,4 +180,7 @@ YART_HD float lightSamplerP(const SceneDev& sc, uint32_t lightIdx) {   // light-
   return l.power / sc.totalPower * (1.0f - pInf);
 }
 
+#if YART_RELAXED_FP == 1
+#pragma clang fp contract(off)
+#endif
 }  // namespace yart_hip

@@ -15,6 +15,10 @@
 //   k_probe_*       diagnostics used by the parity tests.
 // The wavefront (queue-based) pipeline lives in wavefront.hip.inc.
 #include <hip/hip_runtime.h>
+#if defined(YART_EXP_SORT)
+#include <cstring>
+#include <rocprim/rocprim.hpp>      // measurement build only (exp_sort.inc)
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -461,6 +465,10 @@ struct StageTimer {
 struct BatchInfo { uint32_t c0, n, wave, waveSamples, samplesTaken, totalSamples; };
 typedef std::function<bool(const BatchInfo&)> BatchHook;
 
+#if defined(YART_EXP_SORT)
+#include "exp_sort.inc"      // measurement build only (tools/variant_ab.py): traversal kernels over a (cell, octant)-sorted copy of their queue
+#endif
+
 bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRenderParams& p, float* dOut,
                     hipStream_t stream, YartStats* stats, const BatchHook* hook = nullptr) {
   bool aborted = false;
@@ -670,8 +678,14 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             // by far (shadow rays of bounce 0: 35 vs 55 ms).
             if (bounce == 0 && cameraOneRay)
               hipLaunchKernelGGL(kExtendCamera, dim3(gridExtendCamera), dim3(kBlock), 0, stream, a);
-            else
+            else {
+#if defined(YART_EXP_SORT)
+              WfArgs as = a;
+              if (bounce >= 1 && expSortQueue(s, as, false, stream, tLean)) hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, as);
+              else
+#endif
               hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
+            }
             tLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryE, dim3(gridRetryE), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
@@ -690,7 +704,15 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           } else {
             tShadowLean.begin(stream);
+#if defined(YART_EXP_SORT)
+            {
+              WfArgs as = a;
+              if (expSortQueue(s, as, true, stream, tShadowLean)) hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, as);
+              else hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
+            }
+#else
             hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
+#endif
             tShadowLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryS, dim3(gridRetryS), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);

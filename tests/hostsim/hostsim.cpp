@@ -314,7 +314,7 @@ static int doSelfTest() {
       std::vector<uint64_t> entries(size_t(dims) * nPix), hash(dims + 3);
       for (uint32_t i = 0; i < nPix; i++) { px[i] = rng.next() % 4000u; py[i] = rng.next() % 3000u; }
       for (uint32_t d = 0; d < dims; d++)
-        for (uint32_t i = 0; i < nPix; i++) entries[size_t(d) * nPix + i] = samplerTableEntry(cfg, encodeMorton2(px[i], py[i]), d);
+        for (uint32_t i = 0; i < nPix; i++) entries[size_t(i) * dims + d] = samplerTableEntry(cfg, encodeMorton2(px[i], py[i]), d);
       for (uint32_t d = 0; d < dims + 3; d++) hash[d] = hashDim(d);
       SamplerConfig tcfg = cfg;
       tcfg.tab.entries = entries.data(); tcfg.tab.hash = hash.data(); tcfg.tab.sobol1 = byteTab.data();
@@ -373,6 +373,12 @@ static int doSelfTest() {
         while (idx < n && cdf[idx] < uj) idx++;
         guide.push_back(idx);
       }
+      // the interleaved records the environment sampling walks (lights.hpp::pc1dSampleRecords), strides 2 and 4
+      std::vector<float> rec2(size_t(n + 1) * 2, 0.0f), rec4(size_t(n + 1) * 4, 0.0f);
+      for (uint32_t k = 0; k <= n; k++) {
+        rec2[size_t(k) * 2] = rec4[size_t(k) * 4] = cdf[k];
+        if (k < n) rec2[size_t(k) * 2 + 1] = rec4[size_t(k) * 4 + 1] = func[k];
+      }
       for (uint32_t rep = 0; rep < 4000; rep++) {
         float u = float(rng.next() & 0xffffffu) * 0x1p-24f;
         if (rep % 7 == 0) u = cdf[rng.next() % (n + 1)];        // exactly on a CDF value
@@ -382,6 +388,14 @@ static int doSelfTest() {
         float x1 = pc1dSample(func.data(), cdf.data(), n, integral, 0.0f, 1.0f, u, pdf1, o1, guide.data(), K);
         if (o0 != o1 || std::memcmp(&x0, &x1, 4) != 0 || std::memcmp(&pdf0, &pdf1, 4) != 0) {
           std::fprintf(stderr, "selftest: guided CDF search mismatch n=%u kind=%d u=%a (%u vs %u)\n", n, kind, u, o0, o1);
+          return 3;
+        }
+        float pdf2, pdf3; uint32_t o2, o3;
+        const float x2 = pc1dSampleRecords<2>(rec2.data(), n, integral, cdf[1], u, pdf2, o2, guide.data(), K);
+        const float x3 = pc1dSampleRecords<4>(rec4.data(), n, integral, cdf[1], u, pdf3, o3, nullptr, 0);
+        if (o0 != o2 || o0 != o3 || std::memcmp(&x0, &x2, 4) != 0 || std::memcmp(&x0, &x3, 4) != 0 || std::memcmp(&pdf0, &pdf2, 4) != 0 ||
+            std::memcmp(&pdf0, &pdf3, 4) != 0) {
+          std::fprintf(stderr, "selftest: record-form CDF search mismatch n=%u kind=%d u=%a\n", n, kind, u);
           return 3;
         }
         checked++;

@@ -5,5 +5,5 @@ set -e
 cd "$(dirname "$0")/../yart_amd/csrc"
 mkdir -p ../_variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
-  -fhip-fp32-correctly-rounded-divide-sqrt $2 $EXTRA_TAIL -shared -o ../_variants/$1.so yart_hip.hip _gen/lut_data.cpp -lz -ldl
+  -fhip-fp32-correctly-rounded-divide-sqrt $2 -shared -o ../_variants/$1.so yart_hip.hip _gen/lut_data.cpp -lz -ldl
 echo built $1

@@ -9,9 +9,6 @@
 #include "scene_types.hpp"
 
 namespace yart_hip {
-#if YART_RELAXED_FP == 1
-#pragma clang fp contract(fast)     // measurement build only (tools/relaxed_fp_ab.py): fused multiply-adds in BSDF / light evaluation
-#endif
 
 // ---------------------------------------------------------------------------
 // Textures — repeat wrap, 4-tap bilinear, u8/255, gamma-2 decode for sRGB typed
@@ -91,6 +88,22 @@ YART_HD float texelChannel(const TexDev& t, uint32_t word, uint32_t c) {
 struct TexQuad { uint32_t w00, w01, w10, w11; };               // the four taps of a u8 texture
 YART_HD TexQuad texQuad(const SceneDev& sc, const TexDev& t, const TexTaps& k) {
   TexQuad q;
+  if (sc.texQuads != nullptr) {
+    // one footprint record = the same four texels (texture.cpp:21-35 picks them; k.i00 = y * width + x names the record)
+    const uint8_t* base = sc.texQuads + size_t(t.quadOffset) * 16u;
+    if (t.channels >= 3) {
+      const u4 v = *reinterpret_cast<const u4*>(base + size_t(k.i00) * 16u);
+      q.w00 = v.x; q.w01 = v.y; q.w10 = v.z; q.w11 = v.w;
+    } else if (t.channels == 2) {
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(base + size_t(k.i00) * 8u);
+      const uint32_t a = p[0], b = p[1];
+      q.w00 = a & 0xffffu; q.w01 = a >> 16; q.w10 = b & 0xffffu; q.w11 = b >> 16;
+    } else {
+      const uint32_t a = *reinterpret_cast<const uint32_t*>(base + size_t(k.i00) * 4u);
+      q.w00 = a & 0xffu; q.w01 = (a >> 8) & 0xffu; q.w10 = (a >> 16) & 0xffu; q.w11 = a >> 24;
+    }
+    return q;
+  }
   q.w00 = texelWord(sc, t, k.i00); q.w01 = texelWord(sc, t, k.i01);
   q.w10 = texelWord(sc, t, k.i10); q.w11 = texelWord(sc, t, k.i11);
   return q;
@@ -113,6 +126,12 @@ YART_HD f3 texSample3(const SceneDev& sc, int32_t tex, f2 uv) {
   const TexDev t = sc.textures[tex];
   texTally(t);
   const TexTaps k = texTaps(t, uv);
+  if (t.isFloat && t.channels == 3 && sc.texQuads != nullptr) {
+    // float RGB (environment maps): the four taps' twelve floats are one 64-byte record (tap-major, then channel)
+    const f4* r = reinterpret_cast<const f4*>(sc.texQuads + size_t(t.quadOffset) * 16u + size_t(k.i00) * 64u);
+    const f4 a = r[0], b = r[1], c = r[2];           // a = {t00.rgb, t01.r}  b = {t01.gb, t10.rg}  c = {t10.b, t11.rgb}
+    return mk3(bilerp1(a.x, a.w, b.z, c.y, k.u, k.v), bilerp1(a.y, b.x, b.w, c.z, k.u, k.v), bilerp1(a.z, b.y, c.x, c.w, k.u, k.v));
+  }
   const TexQuad q = texQuadOrZero(sc, t, k);
   return mk3(texSampleChannel(sc, t, k, q, 0), texSampleChannel(sc, t, k, q, 1), texSampleChannel(sc, t, k, q, 2));
 }
@@ -149,39 +168,35 @@ YART_HD float trilerp8(const float* x, float u, float v, float w) {    // math_b
   return ((((((x[0] * up * vp * wp + x[1] * up * vp * w) + x[2] * up * v * wp) + x[3] * up * v * w) +
             x[4] * u * vp * wp) + x[5] * u * vp * w) + x[6] * u * v * wp) + x[7] * u * v * w;
 }
+// The interpolated lookups read the footprint copies of the tables (LutDev::fp*: the values of one lookup side by side):
+// the same floats in the same formula, one or two 16-byte loads instead of 2-8 scattered ones.
 YART_HD float ggxE(const float* lut, float cosTheta, float r) {        // luts.hpp:33-44
   float ro = r * 31.0f, co = cosTheta * 31.0f;
   uint32_t ri = sizeTClamp(ro, 30), ci = sizeTClamp(co, 30);
   ro -= float(ri); co -= float(ci);
-  const float* E = lut + LutDev::E;
-  float d00 = E[ri * 32 + ci], d01 = E[ri * 32 + ci + 1];
-  float d10 = E[(ri + 1) * 32 + ci], d11 = E[(ri + 1) * 32 + ci + 1];
-  return bilerp1(d00, d01, d10, d11, ro, co);
+  const f4 e = *reinterpret_cast<const f4*>(lut + LutDev::fpE + (ri * 32 + ci) * 4);   // d00, d01, d10, d11
+  return bilerp1(e.x, e.y, e.z, e.w, ro, co);
 }
 YART_HD float ggxEavg(const float* lut, float r) {                     // luts.hpp:52-57
   uint32_t ri = sizeTClamp(r * 31.0f, 30);
   float ro = r * 31.0f - float(ri);
-  const float* T = lut + LutDev::Eavg;
-  return lerpf(T[ri], T[ri + 1], ro);
+  const f2 t = *reinterpret_cast<const f2*>(lut + LutDev::fpEavg + ri * 4);
+  return lerpf(t.x, t.y, ro);
 }
 YART_HD float ggxBaseE(const float* lut, float f0, float r, float cosTheta) {   // luts.hpp:68-97
   float f0o = f0 * 15.0f, ro = r * 15.0f, co = cosTheta * 15.0f;
   uint32_t f0i = sizeTClamp(f0o, 14), ri = sizeTClamp(ro, 14), ci = sizeTClamp(co, 14);
   f0o -= float(f0i); ro -= float(ri); co -= float(ci);
-  const float* T = lut + LutDev::baseE;
-  float vals[8];
-  for (uint32_t a = 0; a < 2; a++)
-    for (uint32_t b = 0; b < 2; b++)
-      for (uint32_t c = 0; c < 2; c++)
-        vals[a * 4 + b * 2 + c] = T[((f0i + a) * 16 + (ri + b)) * 16 + (ci + c)];
+  const f4* T = reinterpret_cast<const f4*>(lut + LutDev::fpBaseE + ((f0i * 16 + ri) * 16 + ci) * 8);
+  const f4 lo = T[0], hi = T[1];
+  const float vals[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   return trilerp8(vals, f0o, ro, co);
 }
 YART_HD float ggxBaseEavg(const float* lut, float f0, float r) {       // luts.hpp:106-116
   uint32_t f0i = sizeTClamp(f0 * 15.0f, 14), ri = sizeTClamp(r * 15.0f, 14);
   float f0o = f0 * 15.0f - float(f0i), ro = r * 15.0f - float(ri);
-  const float* T = lut + LutDev::baseEavg;
-  return bilerp1(T[f0i * 16 + ri], T[f0i * 16 + ri + 1], T[(f0i + 1) * 16 + ri],
-                 T[(f0i + 1) * 16 + ri + 1], f0o, ro);
+  const f4 t = *reinterpret_cast<const f4*>(lut + LutDev::fpBaseEavg + (f0i * 16 + ri) * 4);
+  return bilerp1(t.x, t.y, t.z, t.w, f0o, ro);
 }
 YART_HD float ggxGlassE(const float* lut, float ior, float r, float cosTheta) {   // luts.hpp:126-158
   bool inv = ior < 1.0f;
@@ -190,12 +205,9 @@ YART_HD float ggxGlassE(const float* lut, float ior, float r, float cosTheta) { 
   uint32_t f0i = sizeTClamp(f0 * 15.0f, 14), ri = sizeTClamp(r * 15.0f, 14),
            ci = sizeTClamp(cosTheta * 15.0f, 14);
   float f0o = f0 * 15.0f - float(f0i), ro = r * 15.0f - float(ri), co = cosTheta * 15.0f - float(ci);
-  const float* T = lut + (inv ? LutDev::glassInvE : LutDev::glassE);
-  float vals[8];
-  for (uint32_t a = 0; a < 2; a++)
-    for (uint32_t b = 0; b < 2; b++)
-      for (uint32_t c = 0; c < 2; c++)
-        vals[a * 4 + b * 2 + c] = T[((f0i + a) * 16 + (ci + b)) * 16 + (ri + c)];
+  const f4* T = reinterpret_cast<const f4*>(lut + (inv ? LutDev::fpGlassInvE : LutDev::fpGlassE) + ((f0i * 16 + ci) * 16 + ri) * 8);
+  const f4 lo = T[0], hi = T[1];
+  const float vals[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   return trilerp8(vals, f0o, co, ro);
 }
 
@@ -720,7 +732,4 @@ YART_HD f3 bsdfNormal(const SceneDev& sc, const MaterialDev& mt, f3 n, f4 t, f2 
   return sn;
 }
 
-#if YART_RELAXED_FP == 1
-#pragma clang fp contract(off)
-#endif
 }  // namespace yart_hip

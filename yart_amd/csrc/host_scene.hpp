@@ -46,6 +46,7 @@ struct HostImage {
   std::vector<TexDev> textures;
   std::vector<uint8_t> texU8;
   std::vector<float> texF32;
+  size_t texQuadUnits = 0;                         // size of the device-side footprint records, in 16-byte units (TexDev::quadOffset)
   std::vector<LightDev> lights;
   std::vector<EnvDev> envs;
   std::vector<float> envData;
@@ -115,6 +116,48 @@ inline float triangleAreaHost(f3 p0, f3 p1, f3 p2) {       // primitives.hpp:24-
 // true, or returns false to leave the mesh to the host builder — the two give the same bytes
 typedef bool (*MeshBvhFn)(void* ctx, const float* positions, uint32_t nVerts, const uint32_t* faces, uint32_t stride, uint32_t nFaces,
                           std::vector<BvhNode>& nodes, std::vector<uint32_t>& indices);
+// Footprint copies of the interpolated LUTs (LutDev::fp*): what one lookup reads, side by side. `lut` holds the reference's
+// tables (LutDev::E .. glassInvEavg); it is grown to LutDev::totalWithFootprints.
+inline void appendLutFootprints(std::vector<float>& lut) {
+  lut.resize(LutDev::totalWithFootprints);
+  {
+    float* L = lut.data();
+    auto at = [&](uint32_t table, uint32_t i) { return L[table + i]; };
+    for (uint32_t r = 0; r < 31; r++)
+      for (uint32_t c = 0; c < 32; c++) {
+        float* o = L + LutDev::fpE + (r * 32 + c) * 4;
+        const uint32_t c1 = c + 1 < 32 ? c + 1 : c;              // (c = 31 is never a base index: sizeTClamp caps at 30)
+        o[0] = at(LutDev::E, r * 32 + c); o[1] = at(LutDev::E, r * 32 + c1);
+        o[2] = at(LutDev::E, (r + 1) * 32 + c); o[3] = at(LutDev::E, (r + 1) * 32 + c1);
+      }
+    for (uint32_t r = 0; r < 32; r++) {
+      float* o = L + LutDev::fpEavg + r * 4;
+      o[0] = at(LutDev::Eavg, r); o[1] = at(LutDev::Eavg, r + 1 < 32 ? r + 1 : r); o[2] = o[3] = 0.0f;
+    }
+    auto cube = [&](uint32_t src, uint32_t dst) {                 // record (i, j, k): src[(i+a)*256 + (j+b)*16 + (k+c)] at a*4 + b*2 + c
+      for (uint32_t i = 0; i < 15; i++)
+        for (uint32_t j = 0; j < 16; j++)
+          for (uint32_t k = 0; k < 16; k++) {
+            float* o = L + dst + ((i * 16 + j) * 16 + k) * 8;
+            for (uint32_t a = 0; a < 2; a++)
+              for (uint32_t b = 0; b < 2; b++)
+                for (uint32_t c = 0; c < 2; c++) {
+                  const uint32_t jj = j + b < 16 ? j + b : j, kk = k + c < 16 ? k + c : k;    // (15 is never a base index)
+                  o[a * 4 + b * 2 + c] = at(src, ((i + a) * 16 + jj) * 16 + kk);
+                }
+          }
+    };
+    cube(LutDev::baseE, LutDev::fpBaseE); cube(LutDev::glassE, LutDev::fpGlassE); cube(LutDev::glassInvE, LutDev::fpGlassInvE);
+    for (uint32_t i = 0; i < 15; i++)
+      for (uint32_t j = 0; j < 16; j++) {
+        float* o = L + LutDev::fpBaseEavg + (i * 16 + j) * 4;
+        const uint32_t j1 = j + 1 < 16 ? j + 1 : j;
+        o[0] = at(LutDev::baseEavg, i * 16 + j); o[1] = at(LutDev::baseEavg, i * 16 + j1);
+        o[2] = at(LutDev::baseEavg, (i + 1) * 16 + j); o[3] = at(LutDev::baseEavg, (i + 1) * 16 + j1);
+      }
+  }
+}
+
 inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullptr, void* bvhCtx = nullptr) {
   require(d.n_nodes >= 1 && d.nodes, "scene needs a root node");
   require(d.n_materials == 0 || d.materials, "materials pointer is null");
@@ -139,6 +182,12 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
       const uint8_t* p = static_cast<const uint8_t*>(t.data);
       im.texU8.insert(im.texU8.end(), p, p + n);
       while (im.texU8.size() % 4) im.texU8.push_back(0);
+    }
+    {
+      const size_t units = (size_t(t.width) * t.height * texQuadRecordBytes(t.channels, td.isFloat) + 15u) / 16u;
+      require(im.texQuadUnits + units < (size_t(1) << 32), "textures: more than 64 GB of footprint records");
+      td.quadOffset = uint32_t(im.texQuadUnits);
+      im.texQuadUnits += units;
     }
     im.textures.push_back(td);
   }
@@ -499,6 +548,23 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
         appendGuide(im.envData.data() + e.margCdfOffset, h, e.guideKh);
         for (uint32_t y = 0; y < h; y++) appendGuide(im.envData.data() + e.cdfOffset + size_t(y) * (w + 1), w, e.guideKw);
       }
+      {   // interleaved copies for the sampling walk (EnvDev::pairOffset)
+        while (im.envData.size() % 4u) im.envData.push_back(0.0f);          // 16-byte aligned records
+        e.pairOffset = uint32_t(im.envData.size());
+        std::vector<float> pairs(size_t(h + 1) * 4u + size_t(h) * (w + 1) * 2u, 0.0f);
+        const float* D = im.envData.data();
+        for (uint32_t k = 0; k <= h; k++) {
+          pairs[size_t(k) * 4u] = D[e.margCdfOffset + k];
+          if (k < h) { pairs[size_t(k) * 4u + 1u] = D[e.rowIntOffset + k]; pairs[size_t(k) * 4u + 2u] = D[e.cdfOffset + size_t(k) * (w + 1) + 1u]; }
+        }
+        float* rows = pairs.data() + size_t(h + 1) * 4u;
+        for (uint32_t y = 0; y < h; y++)
+          for (uint32_t k = 0; k <= w; k++) {
+            rows[(size_t(y) * (w + 1) + k) * 2u] = D[e.cdfOffset + size_t(y) * (w + 1) + k];
+            if (k < w) rows[(size_t(y) * (w + 1) + k) * 2u + 1u] = D[e.funcOffset + size_t(y) * w + k];
+          }
+        im.envData.insert(im.envData.end(), pairs.begin(), pairs.end());
+      }
       ld.envOffset = uint32_t(im.envs.size());
       im.envs.push_back(e);
       im.infiniteLights.push_back(i);
@@ -513,7 +579,7 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
 
   // ---- LUTs + Sobol dimension-1 matrix ------------------------------------------
   im.lut.assign(embeddedLutTables(), embeddedLutTables() + LutDev::sobol);
-  im.lut.resize(LutDev::total);
+  appendLutFootprints(im.lut);
   for (uint32_t k = 0; k < 52; k++) {
     uint32_t bits = sobolDim1Column(k);
     std::memcpy(&im.lut[LutDev::sobol + k], &bits, 4);

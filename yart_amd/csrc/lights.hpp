@@ -6,9 +6,6 @@
 #include "bsdf.hpp"
 
 namespace yart_hip {
-#if YART_RELAXED_FP == 1
-#pragma clang fp contract(fast)     // measurement build only (tools/relaxed_fp_ab.py): fused multiply-adds in BSDF / light evaluation
-#endif
 
 struct LightSample {         // core/light.hpp:10-15
   f3 Li, wi, p, n;
@@ -71,33 +68,52 @@ YART_HD float envPdf(const SceneDev& sc, const LightDev& l, f3 wi) {  // light.c
   float pdf = sc.envData[e.funcOffset + iv * e.w + iu] / e.margIntegral;
   return pdf / (4.0f * kPi);
 }
+// PiecewiseConstant1D::sample (sampling.cpp:5-34, as pc1dSample above) over interleaved records: record k = STRIDE floats,
+// [0] = cdf[k], [1] = func[k]. cdf1 = cdf[1] (the reference's normalisation typo, Appendix A.7). Returns the record index.
+template <uint32_t STRIDE>
+YART_HD float pc1dSampleRecords(const float* rec, uint32_t n, float integral, float cdf1, float u, float& pdf, uint32_t& offset,
+                                const uint32_t* guide, uint32_t K) {
+  uint32_t first = 1, size = n - 1;
+  if (guide != nullptr) {
+    uint32_t j = u >= 0.0f ? uint32_t(u * float(K)) : 0u;
+    if (j > K - 1u) j = K - 1u;
+    first = guide[j];
+    size = guide[j + 1u] - first;
+  }
+  while (size > 0) {
+    const uint32_t half = size >> 1, middle = first + half;
+    if (rec[size_t(middle) * STRIDE] < u) { first = middle + 1; size -= half + 1; }
+    else size = half;
+  }
+  uint32_t o = first - 1;
+  if (o > n - 1) o = n - 1;
+  offset = o;
+  const float cdfO = rec[size_t(o) * STRIDE], funcO = rec[size_t(o) * STRIDE + 1u];
+  float du = u - cdfO;
+  if (cdf1 - cdfO > 0) du /= cdf1 - cdfO;
+  pdf = (integral > 0) ? funcO / integral : 0.0f;
+  return lerpf(0.0f, 1.0f, (float(o) + du) / float(n));
+}
 YART_HD LightSample envSample(const SceneDev& sc, const LightDev& l, f2 u) {   // light.cpp:219-238
   const EnvDev& e = sc.envs[l.envOffset];
   float pdf1, pdf0;
   uint32_t ov, ou;
-  // marginal over v with u.y, then conditional row with u.x (sampling.cpp:36-43)
+  // marginal over v with u.y, then conditional row with u.x (sampling.cpp:36-43), on the interleaved copies of the tables
+  // (EnvDev::pairOffset): the marginal record of the chosen row brings the row's integral and cdf[1] with it
   const uint32_t* gm = e.guideKh ? sc.envGuide + e.guideOffset : nullptr;
-#if defined(YART_EXP_ENV_NOCDF)      // timing experiment only (wrong frames): no CDF searches, a uniform sample of the map
-  float d1 = u.y, d0 = u.x; pdf1 = 1.0f; pdf0 = 1.0f; ov = 0; ou = 0; (void)gm;
-#else
-  float d1 = pc1dSample(sc.envData + e.rowIntOffset, sc.envData + e.margCdfOffset, e.h, e.margIntegral,
-                        0.0f, 1.0f, u.y, pdf1, ov, gm, e.guideKh);
-  float rowInt = sc.envData[e.rowIntOffset + ov];
+  const float* marg = sc.envData + e.pairOffset;
+  float d1 = pc1dSampleRecords<4>(marg, e.h, e.margIntegral, marg[4], u.y, pdf1, ov, gm, e.guideKh);
+  const float rowInt = marg[size_t(ov) * 4u + 1u], rowCdf1 = marg[size_t(ov) * 4u + 2u];
   const uint32_t* gr = e.guideKw ? sc.envGuide + e.guideOffset + (e.guideKh + 1u) + size_t(ov) * (e.guideKw + 1u) : nullptr;
-  float d0 = pc1dSample(sc.envData + e.funcOffset + ov * e.w, sc.envData + e.cdfOffset + ov * (e.w + 1),
-                        e.w, rowInt, 0.0f, 1.0f, u.x, pdf0, ou, gr, e.guideKw);
-#endif
+  const float* row = marg + size_t(e.h + 1u) * 4u + size_t(ov) * (e.w + 1u) * 2u;
+  float d0 = pc1dSampleRecords<2>(row, e.w, rowInt, rowCdf1, u.x, pdf0, ou, gr, e.guideKw);
   float pdf = pdf0 * pdf1;
   if (pdf == 0.0f) return emptyLightSample();
   f2 uv = mk2(d0, d1);
   f3 wi = mulVector(l.xf.fwd, invOctahedralUV(uv));
   pdf /= e.surfaceArea;
   LightSample s;
-#if defined(YART_EXP_ENV_NOTEX)       // timing experiment only (wrong frames): no radiance lookup
-  s.Li = mk3(1.0f);
-#else
   s.Li = envLe(sc, l, uv);
-#endif
   s.wi = wi;
   s.p = (wi * 2.0f) * l.radius;
   s.n = -wi;
@@ -180,7 +196,4 @@ YART_HD float lightSamplerP(const SceneDev& sc, uint32_t lightIdx) {   // light-
   return l.power / sc.totalPower * (1.0f - pInf);
 }
 
-#if YART_RELAXED_FP == 1
-#pragma clang fp contract(off)
-#endif
 }  // namespace yart_hip

@@ -23,7 +23,7 @@ namespace yart_hip {
 // (Tables for the low digits as well — 80 B instead of 8 B per dimension and pixel — were measured in round 2 and
 // lose: the gathers cost more than the hashes, profiles/r2_sampler_rows_kernel_stats.txt; removed.)
 struct SamplerTables {
-  const uint64_t* entries = nullptr;   // [dims][stride]
+  const uint64_t* entries = nullptr;   // [stride = pixels][dims]: the draws of one shading step (dimensions d .. d + 7) of a path lie in one or two sectors
   const uint64_t* hash = nullptr;      // [dims + 3]
   const uint32_t* sobol1 = nullptr;    // [8][256]: XOR of the matrix columns selected by byte b of the index
   uint32_t dims = 0, stride = 0;
@@ -180,7 +180,7 @@ YART_HD uint64_t samplerTableEntry(const SamplerConfig& c, uint64_t pixelMorton,
 
 YART_HD uint64_t getSampleIndex(const Sampler& s, const SamplerConfig& c) {
   if (c.tab.entries == nullptr || s.dim >= c.tab.dims) return getSampleIndexDirect(s, c);
-  const uint64_t e = c.tab.entries[size_t(s.dim) * c.tab.stride + s.pix];
+  const uint64_t e = c.tab.entries[size_t(s.pix) * c.tab.dims + s.dim];
   const int lastDigit = int(c.log2spp & 1u);
   const uint64_t dimMix = uint64_t(0x55555555u * s.dim);
   uint64_t index = (e & 0xffffffull) << c.log2spp;

@@ -32,7 +32,17 @@ struct TexDev {            // core/texture.hpp:21-49
   uint32_t width, height, channels;
   uint32_t type;           // TEX_*
   uint32_t isFloat;
+  // 2x2 footprint records (device only, SceneDev::texQuads; built by k_tex_quads at upload): record (x, y) holds the four
+  // bilinear taps (x, y), (x, y+1), (x+1, y), (x+1, y+1) side by side, so that one lookup is ONE aligned access of one 64-byte
+  // sector instead of taps in two texel rows. u8: 4 / 8 / 16 bytes per record for 1 / 2 / 3-4 channels (a tap = one word,
+  // channel c in byte c); float: 4 taps x channels floats, padded to a power of two (RGB: 64 bytes). In units of 16 bytes.
+  uint32_t quadOffset;
+  uint32_t pad;
 };
+YART_HD uint32_t texQuadRecordBytes(uint32_t channels, uint32_t isFloat) {
+  if (isFloat) return channels == 1 ? 16u : channels == 2 ? 32u : 64u;
+  return channels == 1 ? 4u : channels == 2 ? 8u : 16u;
+}
 
 struct MaterialDev {       // bsdf/parametric.hpp:52-77
   f3 base; float cTrans;
@@ -120,7 +130,12 @@ struct EnvDev {            // ImageInfiniteLight + PiecewiseConstant2D (light.cp
   float surfaceArea;       // light.cpp:192-196
   // guide tables for the CDF searches (lights.hpp::pc1dSample): SceneDev::envGuide + guideOffset holds
   // guideKh + 1 entries for the marginal CDF, then h rows of guideKw + 1 entries; 0 = none
-  uint32_t guideOffset, guideKw, guideKh, pad0;
+  uint32_t guideOffset, guideKw, guideKh;
+  // the same tables interleaved for the SAMPLING walk (lights.hpp::envSample), so that what one step of it reads lies in one
+  // sector: at envData + pairOffset first h + 1 marginal records {margCdf[k], rowInt[k], cdf_k[1], 0} (the row integral and
+  // the row's cdf[1] — the reference's normalisation typo needs it — arrive with the marginal search's own last read), then
+  // h rows of w + 1 records {cdf[k], func[k]} (func[w] = 0). Values are copies: same floats, same arithmetic.
+  uint32_t pairOffset;
 };
 
 struct CameraDev {         // core/camera.hpp:13-59
@@ -139,6 +154,16 @@ struct LutDev {            // bsdf/luts.hpp:14-24 — float offsets into lutData
   static constexpr uint32_t E = 0, Eavg = 1024, baseE = 1056, baseEavg = 5152, glassE = 5408,
                             glassEavg = 9504, glassInvE = 9760, glassInvEavg = 13856,
                             sobol = 14112, total = 14164;
+  // Footprint copies of the tables above (host_scene.hpp::appendLutFootprints): record (i, j[, k]) holds the 2 / 4 / 8 values
+  // one interpolated lookup reads, in the order the interpolation formula takes them, so that a lookup is one or two aligned
+  // 16-byte loads instead of 2-8 scattered ones. Same floats, same arithmetic. Float offsets, 16-byte aligned.
+  static constexpr uint32_t fpE = 14164,                       // [31][32] x 4: E[ri][ci], E[ri][ci+1], E[ri+1][ci], E[ri+1][ci+1]
+                            fpEavg = fpE + 31 * 32 * 4,        // [32] x 2 (padded to 4): Eavg[ri], Eavg[ri+1]
+                            fpBaseE = fpEavg + 32 * 4,         // [15][16][16] x 8: baseE[f0i+a][ri+b][ci+c] at a*4 + b*2 + c
+                            fpBaseEavg = fpBaseE + 15 * 16 * 16 * 8,   // [15][16] x 4
+                            fpGlassE = fpBaseEavg + 15 * 16 * 4,       // [15][16][16] x 8: glassE[f0i+a][ci+b][ri+c], record (f0i, ci, ri)
+                            fpGlassInvE = fpGlassE + 15 * 16 * 16 * 8,
+                            totalWithFootprints = fpGlassInvE + 15 * 16 * 16 * 8;
 };
 
 // Everything a kernel needs, passed by value as a kernel argument (pointers into HBM).
@@ -159,6 +184,7 @@ struct SceneDev {
   const TexDev* textures;
   const uint8_t* texU8;
   const float* texF32;
+  const uint8_t* texQuads;     // 2x2 footprint records of every texture (TexDev::quadOffset), nullptr on the host (tests/hostsim)
   const LightDev* lights;
   const EnvDev* envs;
   const float* envData;

@@ -16,10 +16,6 @@
 #pragma once
 #include "integrator.hpp"
 
-#ifndef YART_LAZY_DRAWS
-#define YART_LAZY_DRAWS 0
-#endif
-
 namespace yart_hip {
 
 struct WfState {
@@ -272,15 +268,11 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
   const MaterialDev& mt = sc.materials[hit.material];
   f2 u = get2D(p.smp, rc.sampler, sobol);
   float uc = get1D(p.smp, rc.sampler);
-#if YART_LAZY_DRAWS
   // A draw is a pure function of (pixel, sample, dimension): the sampler's state is the dimension counter alone. The third
   // draw (uc2, parametric.cpp:226-251) only chooses between the clearcoat / metallic / dielectric lobes; it is evaluated
   // below, once the material is known, and only where it can decide anything.
   Sampler smpUc2 = p.smp;
   p.smp.dim++;
-#else
-  float uc2 = get1D(p.smp, rc.sampler);
-#endif
   SR_MARK(3);                                                   // sampler: one 2D + two 1D draws
   const f3 wo = -p.d;
   // one shading frame and one material fetch for sample / f / pdf (core/bsdf.cpp:5-58 builds the
@@ -288,12 +280,10 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
   const Frame fr = shadingFrame(hit.n, hit.tg);
   const f3 woLocal = wtl(fr, wo);
   const MatEval me = matEvaluate(sc, mt, hit.uv);
-#if YART_LAZY_DRAWS
   // c = m = t = 0 (no clearcoat, metal or transmission — the bulk of most scenes): the three selection probabilities are 0
   // and `uc2 < p` is false for every uc2 in [0, 1) (bsdfSampleImplE), so its ~170 instructions of index hashing are skipped
   float uc2 = 0.0f;
   if (!(me.c == 0.0f && me.m == 0.0f && me.t == 0.0f)) uc2 = get1D(smpUc2, rc.sampler);
-#endif
   SR_MARK(4);                                                   // shading frame + material / texture fetch
   BsdfSample res = bsdfSampleImplE(sc, mt, me, woLocal, hit.uv, u, uc, uc2, regularized);
   res.wi = ltw(fr, res.wi);
@@ -326,25 +316,17 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
     p.flags = fl;
   }
   SR_MARK(6);                                                   // emission MIS, throughput, new ray stored
-#if defined(YART_EXP_SKIP_NEE)      // timing experiment only (wrong frames): the shade kernel without its NEE block
-  const bool nee = false;
-#else
   const bool nee = !(res.scatter & (SC_EMITTED | SC_SPECULAR));
-#endif
 
   bool shadow = false;
   if (nee) {                                                    // L += attenuation * Ld(...)   (:79-80)
     if (sc.nLights != 0) {                                      // Ld set-up (:111-124)
-#if YART_LAZY_DRAWS
       // the light-choice draw: with ONE infinite light and no area light PowerLightSampler::sample returns that light with
       // probability 1 whatever u is (light-sampler.cpp:52-78: pInfinite = 1, index min(0, .)) — the dimension is consumed, the
       // value is not evaluated
       float ucl = 0.0f;
       if (sc.nArea == 0u && sc.nInfinite == 1u) p.smp.dim++;
       else ucl = get1D(p.smp, rc.sampler);
-#else
-      float ucl = get1D(p.smp, rc.sampler);
-#endif
       f2 ul = get2D(p.smp, rc.sampler, sobol);
       SR_MARK(7);                                               // sampler: NEE draws (1D + 2D)
       float pl;

@@ -15,10 +15,6 @@
 //   k_probe_*       diagnostics used by the parity tests.
 // The wavefront (queue-based) pipeline lives in wavefront.hip.inc.
 #include <hip/hip_runtime.h>
-#if defined(YART_EXP_SORT)
-#include <cstring>
-#include <rocprim/rocprim.hpp>      // measurement build only (exp_sort.inc)
-#endif
 
 #include <algorithm>
 #include <chrono>
@@ -262,6 +258,37 @@ __global__ void __launch_bounds__(kBlock) k_probe_hits(ProbeHitArgs a) {
   }
 }
 
+// 2x2 footprint records of one texture (scene_types.hpp TexDev::quadOffset), expanded on the device at upload from the plain
+// texel arrays: record (x, y) = the four taps texture.cpp:21-35 reads for a lookup whose base texel is (x, y)
+struct TexQuadArgs { const uint8_t* u8; const float* f32; TexDev t; uint8_t* out; };
+__global__ void __launch_bounds__(kBlock) k_tex_quads(TexQuadArgs a) {
+  const uint32_t w = a.t.width, h = a.t.height, C = a.t.channels;
+  const uint32_t rec = texQuadRecordBytes(C, a.t.isFloat);
+  const size_t n = size_t(w) * h;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    const uint32_t x = uint32_t(i % w), y = uint32_t(i / w);
+    const uint32_t x1 = x + 1u < w ? x + 1u : x, y1 = y + 1u < h ? y + 1u : y;      // (records of the last column / row are never read)
+    const size_t idx[4] = {size_t(y) * w + x, size_t(y1) * w + x, size_t(y) * w + x1, size_t(y1) * w + x1};
+    uint8_t* o = a.out + i * rec;
+    if (a.t.isFloat) {
+      float* of = reinterpret_cast<float*>(o);
+      for (uint32_t k = 0; k < rec / 4u; k++) of[k] = 0.0f;
+      for (uint32_t tap = 0; tap < 4u; tap++)
+        for (uint32_t c = 0; c < C; c++) of[tap * C + c] = a.f32[size_t(a.t.offset) + C * idx[tap] + c];
+    } else {
+      uint32_t word[4];
+      for (uint32_t tap = 0; tap < 4u; tap++) {
+        word[tap] = 0u;
+        for (uint32_t c = 0; c < C; c++) word[tap] |= uint32_t(a.u8[size_t(a.t.offset) + C * idx[tap] + c]) << (8u * c);
+      }
+      uint32_t* ow = reinterpret_cast<uint32_t*>(o);
+      if (C >= 3u) { ow[0] = word[0]; ow[1] = word[1]; ow[2] = word[2]; ow[3] = word[3]; }
+      else if (C == 2u) { ow[0] = word[0] | (word[1] << 16); ow[1] = word[2] | (word[3] << 16); }
+      else ow[0] = word[0] | (word[1] << 8) | (word[2] << 16) | (word[3] << 24);
+    }
+  }
+}
+
 #include "wavefront_kernels.inc"
 #include "bvh_build_device.inc"
 
@@ -284,7 +311,7 @@ struct YartScene {
   // device copies of the scene image
   DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<Wide4> wideNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
-  DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32;
+  DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32; DevBuf<uint8_t> texQuads;
   DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld; DevBuf<TlasNode> tlas; DevBuf<unsigned long long> nodeBits;
   DevBuf<uint32_t> infiniteLights, areaLights; DevBuf<float> areaPowerCdf; DevBuf<float> lut;
   DevBuf<uint8_t> matClass;                // host_scene.hpp::lobeClass per material
@@ -322,12 +349,22 @@ void uploadScene(YartScene& s) {
     for (const MaterialDev& m : h.materials) cls.push_back(lobeClass(m));
     s.matClass.upload(cls);
   }
+  // the textures' 2x2 footprint records: expanded here from the plain texel arrays just uploaded
+  s.texQuads.ensure(std::max<size_t>(h.texQuadUnits, 1) * 16u);
+  for (const TexDev& t : h.textures) {
+    if (t.width == 0u) continue;
+    TexQuadArgs qa{s.texU8.p, s.texF32.p, t, s.texQuads.p + size_t(t.quadOffset) * 16u};
+    const size_t n = size_t(t.width) * t.height;
+    hipLaunchKernelGGL(k_tex_quads, dim3(uint32_t(std::min<size_t>((n + kBlock - 1) / kBlock, 65535u))), dim3(kBlock), 0, nullptr, qa);
+    HIP_CHECK(hipGetLastError());
+  }
+  HIP_CHECK(hipDeviceSynchronize());
   SceneDev d = h.view();       // counts and totals; pointers replaced below
   d.shadeTris = s.shadeTris.p;
   d.bvhNodes = s.bvhNodes.p; d.wideNodes = s.wideNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
-  d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.lights = s.lights.p; d.envs = s.envs.p;
+  d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.texQuads = s.texQuads.p; d.lights = s.lights.p; d.envs = s.envs.p;
   d.envData = s.envData.p; d.envGuide = s.envGuide.p; d.nodeWorld = s.nodeWorld.p; d.tlas = s.tlas.p; d.nTlas = h.tlas.size() > 1 || (h.tlas.size() == 1 && h.tlas[0].b) ? uint32_t(h.tlas.size()) : 0u; d.infiniteLights = s.infiniteLights.p; d.areaLights = s.areaLights.p;
   d.areaPowerCdf = s.areaPowerCdf.p; d.lut = s.lut.p;
   s.dev = d;
@@ -464,10 +501,6 @@ struct StageTimer {
 // synchronised): the range [c0, c0 + n) of this rank's pixel list. Returning true stops the render after this batch.
 struct BatchInfo { uint32_t c0, n, wave, waveSamples, samplesTaken, totalSamples; };
 typedef std::function<bool(const BatchInfo&)> BatchHook;
-
-#if defined(YART_EXP_SORT)
-#include "exp_sort.inc"      // measurement build only (tools/variant_ab.py): traversal kernels over a (cell, octant)-sorted copy of their queue
-#endif
 
 bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRenderParams& p, float* dOut,
                     hipStream_t stream, YartStats* stats, const BatchHook* hook = nullptr) {
@@ -678,14 +711,8 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             // by far (shadow rays of bounce 0: 35 vs 55 ms).
             if (bounce == 0 && cameraOneRay)
               hipLaunchKernelGGL(kExtendCamera, dim3(gridExtendCamera), dim3(kBlock), 0, stream, a);
-            else {
-#if defined(YART_EXP_SORT)
-              WfArgs as = a;
-              if (bounce >= 1 && expSortQueue(s, as, false, stream, tLean)) hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, as);
-              else
-#endif
+            else
               hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
-            }
             tLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryE, dim3(gridRetryE), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
@@ -704,15 +731,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           } else {
             tShadowLean.begin(stream);
-#if defined(YART_EXP_SORT)
-            {
-              WfArgs as = a;
-              if (expSortQueue(s, as, true, stream, tShadowLean)) hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, as);
-              else hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
-            }
-#else
             hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
-#endif
             tShadowLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryS, dim3(gridRetryS), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);

@@ -248,12 +248,6 @@ YART_HD f3 invOctahedralUV(f2 uv) {                            // math.hpp:168-1
 // from glibc's in the last bit for roughly a quarter of the inputs, which is
 // what made rare paths diverge; these do not.
 // ---------------------------------------------------------------------------
-#ifndef YART_BOUNDED_TRIG
-#define YART_BOUNDED_TRIG 0
-#endif
-#ifndef YART_RELAXED_FP
-#define YART_RELAXED_FP 0      // 1: measurement build — ocml's sinf / cosf / logf / expf and contracted BSDF / light arithmetic (not bit-exact)
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 namespace libm_emul {
 struct SinCosTab { double c0, c1, c2, c3, c4, s1, s2, s3; };
@@ -373,9 +367,6 @@ __device__ __forceinline__ float expf_(float x) {
 // |x| >= 120 tail, whose double-precision sin / cos (Payne-Hanek reduction, ~700 fp64 instructions inlined per call site)
 // can never run for them. NOT valid outside [0, 120).
 __device__ __forceinline__ float ysinf2pi(float y) {
-#if YART_RELAXED_FP
-  return sinf(y);
-#elif YART_BOUNDED_TRIG
   using namespace libm_emul;
   double x = y;
   if (top12(y) < top12(0x1.921FB6p-1f)) {
@@ -385,14 +376,8 @@ __device__ __forceinline__ float ysinf2pi(float y) {
   int n;
   x = reduceFast(x, n);
   return poly(x * quadSign(n), x * x, (n & 2) != 0, n);
-#else
-  return libm_emul::sinf_(y);
-#endif
 }
 __device__ __forceinline__ float ycosf2pi(float y) {
-#if YART_RELAXED_FP
-  return cosf(y);
-#elif YART_BOUNDED_TRIG
   using namespace libm_emul;
   double x = y;
   if (top12(y) < top12(0x1.921FB6p-1f)) {
@@ -402,21 +387,11 @@ __device__ __forceinline__ float ycosf2pi(float y) {
   int n;
   x = reduceFast(x, n);
   return poly(x * quadSign(n + 1), x * x, ((n + 1) & 2) != 0, n ^ 1);
-#else
-  return libm_emul::cosf_(y);
-#endif
 }
-#if YART_RELAXED_FP
-__device__ __forceinline__ float ysinf(float x) { return sinf(x); }
-__device__ __forceinline__ float ycosf(float x) { return cosf(x); }
-__device__ __forceinline__ float ylogf(float x) { return logf(x); }
-__device__ __forceinline__ float yexpf(float x) { return expf(x); }
-#else
 __device__ __forceinline__ float ysinf(float x) { return libm_emul::sinf_(x); }
 __device__ __forceinline__ float ycosf(float x) { return libm_emul::cosf_(x); }
 __device__ __forceinline__ float ylogf(float x) { return libm_emul::logf_(x); }
 __device__ __forceinline__ float yexpf(float x) { return libm_emul::expf_(x); }
-#endif
 #else
 inline float ysinf2pi(float x) { return sinf(x); }
 inline float ycosf2pi(float x) { return cosf(x); }

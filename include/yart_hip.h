@@ -148,10 +148,6 @@ typedef struct YartRenderParams {
                                        since round 2 (measured: shade stage -8.4 % on the McLaren-class scene, -0.5 % on the
                                        Sponza-class one; round 1 bucketed by material index and lost 5 % there) */
 #define YART_FLAG_NO_SHADE_SORT 64u /* shade the queue entries in queue order */
-#define YART_FLAG_WIDE_BVH 128u     /* lean traversal kernels walk a 4-wide re-layout of the reference's binary tree (same boxes,
-                                       same triangle tests; children nearest-first over four). Frames equal the binary walk's bit for bit: rays
-                                       that meet an alpha-tested triangle or two triangles at exactly the same t go to the general
-                                       kernels. Measured slower on the BASELINE scenes, hence opt-in */
 #define YART_FLAG_DIRECT_SAMPLER 8u /* evaluate every ZSobol index digit per draw (no per-render sampler tables) */
 #define YART_FLAG_NO_COMPACTION 32u  /* keep every bounce on the batch-sized path state (no copy of the survivors into a dense one) */
 #define YART_FLAG_GENERAL_TRACE 4u  /* general traversal kernels for every ray instead of lean kernels + retry */

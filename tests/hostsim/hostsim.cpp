@@ -480,105 +480,6 @@ static int doEstimator(int kind, unsigned spp, const char* in, const char* out) 
   return 0;
 }
 
-// widecheck: the 4-wide records of wide_bvh.hpp against the binary tree they re-lay out. For every mesh: every leaf of
-// the binary tree is reachable through exactly one chain of records; and for random rays through the mesh's bounds the
-// closest hit of a plain (unsorted, recursive) walk over the records — the same box test, the same triangle test —
-// has the same t as traverseMesh's walk of the binary tree (the triangle may differ only where two share that t).
-struct WideWalk {
-  const HostImage* im; const MeshDev* mesh; const RayO* ray; float tMin; float best; uint32_t tri; uint64_t boxes, tris;
-  void visit(uint32_t rec) {
-    const Wide4& w = im->wideNodes[mesh->wideOffset + rec];
-    for (int k = 0; k < 4; k++) {
-      if (w.link[k] == kWideEmpty) continue;
-      const float bmin[3] = {w.lo[0][k], w.lo[1][k], w.lo[2][k]}, bmax[3] = {w.hi[0][k], w.hi[1][k], w.hi[2][k]};
-      float d;
-      boxes++;
-      if (!testBox(*ray, tMin, best, bmin, bmax, d) || !(d < best)) continue;
-      const uint32_t link = w.link[k];
-      if ((link >> kSpanShift) == 0u) { visit(link & kLinkIndexMask); continue; }
-      const LeafTri* leaves = im->leafTris.data() + mesh->leafOffset;
-      const uint32_t first = link & kLinkIndexMask, n = leafSpan(leaves, first, link >> kSpanShift);
-      for (uint32_t i = 0; i < n; i++) {
-        const LeafTri& tr = leaves[first + i];
-        tris++;
-        const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]), e1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]), e2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
-        const f3 re2 = cross(ray->d, e2);
-        const float det = dot(e1, re2);
-        if (double(fabsf(det)) < 1e-12) continue;
-        const float inv = 1.0f / det;
-        const f3 b = ray->o - p0;
-        const float u = dot(b, re2) * inv;
-        if (u < 0.0f || u > 1.0f) continue;
-        const f3 be1 = cross(b, e1);
-        const float v = dot(ray->d, be1) * inv;
-        if (v < 0.0f || u + v > 1.0f) continue;
-        const float t = dot(e2, be1) * inv;
-        if (t <= tMin || best <= t) continue;
-        best = t; tri = tr.triIdx;
-      }
-    }
-  }
-};
-static int doWideCheck(const char* scenePath, unsigned raysPerMesh) {
-  auto loaded = loadSceneFile(scenePath);
-  HostImage im = buildHostImage(loaded->desc);
-  // strip alpha / transparency: the binary walk below then never consults a sampler
-  for (auto& l : im.leafTris) l.matFlags &= ~(MAT_HAS_ALPHA | MAT_TRANSPARENT);
-  SceneDev sc = im.view();
-  uint64_t stack[kRefStackDepth];
-  TravStack stk; stk.lds = reinterpret_cast<lds_u64*>(stack); stk.ldsStride = 1; stk.ldsDepth = kRefStackDepth; stk.spill = nullptr; stk.spillStride = 0;
-  size_t rays = 0, hits = 0, triDiffer = 0, records = 0;
-  uint64_t wBoxes = 0, wTris = 0;
-  for (size_t m = 0; m < im.meshes.size(); m++) {
-    const MeshDev& mesh = im.meshes[m];
-    records += mesh.nWide;
-    // leaf coverage: every leaf link exactly once
-    std::vector<uint32_t> seen(mesh.nTris, 0);
-    const LeafTri* leaves = im.leafTris.data() + mesh.leafOffset;
-    for (uint32_t r = 0; r < mesh.nWide; r++)
-      for (int k = 0; k < 4; k++) {
-        const uint32_t link = im.wideNodes[mesh.wideOffset + r].link[k];
-        if (link == kWideEmpty || (link >> kSpanShift) == 0u) continue;
-        const uint32_t first = link & kLinkIndexMask, n = leafSpan(leaves, first, link >> kSpanShift);
-        for (uint32_t i = 0; i < n; i++) seen[first + i]++;
-      }
-    for (uint32_t i = 0; i < mesh.nTris; i++)
-      if (seen[i] != 1) { std::fprintf(stderr, "widecheck: mesh %zu leaf record %u referenced %u times\n", m, i, seen[i]); return 3; }
-    const BvhNode& root = im.bvhNodes[mesh.nodeOffset];
-    kat::Lcg rng(77 + uint32_t(m));
-    for (unsigned k = 0; k < raysPerMesh; k++) {
-      f3 a, b;
-      float* av[3] = {&a.x, &a.y, &a.z}; float* bv[3] = {&b.x, &b.y, &b.z};
-      for (int c = 0; c < 3; c++) {
-        const float lo = root.bmin[c], hi = root.bmax[c], ext = hi - lo;
-        *av[c] = lo - 0.2f * ext + 1.4f * ext * rng.next();
-        *bv[c] = lo + ext * rng.next();
-      }
-      const f3 dir = normalized(b - a);
-      const RayO ray = makeRay(a, dir);
-      HitRec hr; hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
-      f3 att = mk3(1.0f);
-      Sampler dummy; dummy.dim = 0; dummy.morton = 0;
-      AlphaCtx ac; ac.sampler = &dummy; ac.cfg = SamplerConfig{};
-      const bool hit = traverseMesh<false>(sc, mesh, 0, ray, 0.001f, hr, att, stk, ac);
-      WideWalk w{&im, &mesh, &ray, 0.001f, kInf, 0xffffffffu, 0, 0};
-      float dRoot;
-      if (testBox(ray, 0.001f, kInf, root.bmin, root.bmax, dRoot)) w.visit(0);
-      rays++; hits += hit; wBoxes += w.boxes; wTris += w.tris;
-      const bool whit = w.best < kInf;
-      if (hit != whit || (hit && __builtin_bit_cast(uint32_t, hr.t) != __builtin_bit_cast(uint32_t, w.best))) {
-        std::fprintf(stderr, "widecheck: mesh %zu ray %u: binary %d t=%.9g tri %u, wide %d t=%.9g tri %u\n", m, k, int(hit), hr.t, hr.tri,
-                     int(whit), w.best, w.tri);
-        return 4;
-      }
-      if (hit && hr.tri != w.tri) triDiffer++;
-    }
-  }
-  std::printf("{\"widecheck\": \"ok\", \"meshes\": %zu, \"records\": %zu, \"rays\": %zu, \"hits\": %zu, \"same_t_other_triangle\": %zu, "
-              "\"wide_box_tests_per_ray\": %.2f, \"wide_tri_tests_per_ray\": %.2f}\n", im.meshes.size(), records, rays, hits, triDiffer,
-              double(wBoxes) / double(rays ? rays : 1), double(wTris) / double(rays ? rays : 1));
-  return 0;
-}
 
 // bvhcheck: the task-parallel BVH build against the plain recursion, every mesh of a scene, byte for byte
 static int doBvhCheck(const char* scenePath, unsigned threads) {
@@ -614,10 +515,6 @@ static int doBvhCheck(const char* scenePath, unsigned threads) {
 int main(int argc, char** argv) {
   if (argc == 2 && std::string(argv[1]) == "selftest") return doSelfTest();
   if (argc == 4 && std::string(argv[1]) == "bvhcheck") return doBvhCheck(argv[2], unsigned(std::atoi(argv[3])));
-  if (argc == 4 && std::string(argv[1]) == "widecheck") {
-    try { return doWideCheck(argv[2], unsigned(std::atoi(argv[3]))); }
-    catch (const std::exception& e) { std::fprintf(stderr, "hostsim: %s\n", e.what()); return 2; }
-  }
   if (argc == 6 && std::string(argv[1]) == "estimator")
     return doEstimator(std::atoi(argv[2]), unsigned(std::atoi(argv[3])), argv[4], argv[5]);
   if (argc == 8 && std::string(argv[1]) == "tonemap")

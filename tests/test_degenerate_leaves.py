@@ -48,7 +48,6 @@ def test_big_leaves_on_device(built, tmp_path):
     scene = api.DeviceScene(s, device=0)
     want = None
     for name, flags in PIPELINE_FLAGS.items():
-        # (every hit on the stacks is an exact tie between coincident triangles: the 4-wide walk hands such rays to the general kernel)
         img, _ = scene.render(p, flags=flags)
         if want is None:
             want = np.fromfile(ref, np.float32).reshape(img.shape)

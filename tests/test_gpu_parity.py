@@ -35,10 +35,10 @@ def api(built):
 
 PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+shade_sort": 2, "wavefront+general_trace": 4,
                   "wavefront+direct_sampler": 8, "wavefront+no_refill": 16, "wavefront+no_compaction": 32,
-                  "wavefront+no_shade_sort": 64, "wavefront+wide_bvh": 128,
+                  "wavefront+no_shade_sort": 64,
                   # scenes of 64 nodes and more take their candidate windows from the top-level hierarchy by default; the two
                   # forms without it: chunked candidate masks / per-lane walk of the node list by size (262144), the walk (65536)
-                  "wavefront+node_masks": 262144, "wavefront+node_walk": 65536, "wavefront+node_walk+wide_bvh": 65536 | 128}
+                  "wavefront+node_masks": 262144, "wavefront+node_walk": 65536}
 
 
 @pytest.mark.parametrize("pipeline", list(PIPELINE_FLAGS))

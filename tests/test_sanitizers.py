@@ -1,7 +1,7 @@
-"""The device headers and the host side of the library (scene build, .yscn loader, wide records, sampler tables) compiled for
+"""The device headers and the host side of the library (scene build, .yscn loader, sampler tables) compiled for
 the host with AddressSanitizer + UndefinedBehaviorSanitizer (GPU sanitizers are not available on the pool: the CPU build is
-where they run). The binary is tests/hostsim with -fsanitize=address,undefined; it must stay clean on the self test, the wide
-record check, the BVH build check and a golden render — and the render must still be the reference's frame bit for bit."""
+where they run). The binary is tests/hostsim with -fsanitize=address,undefined; it must stay clean on the self test,
+the BVH build check and a golden render — and the render must still be the reference's frame bit for bit."""
 import os
 import subprocess
 
@@ -28,8 +28,7 @@ def san(built):
 
 def test_host_build_is_clean_under_asan_and_ubsan(san, tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
-    for args in (["selftest"], ["widecheck", os.path.join(GOLDEN, "material.yscn"), "4000"],
-                 ["bvhcheck", os.path.join(GOLDEN, "material.yscn"), "3"]):
+    for args in (["selftest"], ["bvhcheck", os.path.join(GOLDEN, "material.yscn"), "3"]):
         r = subprocess.run([san] + args, capture_output=True, text=True, env=env)
         assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, (args, r.stderr[-800:])
     out = os.path.join(tmp_path, "m.f32")

@@ -20,7 +20,6 @@
 #include "bvh_build.hpp"
 #include "sampler.hpp"
 #include "scene_types.hpp"
-#include "wide_bvh.hpp"
 
 namespace yart_hip {
 
@@ -34,7 +33,6 @@ inline uint8_t lobeClass(const MaterialDev& mt) {
 struct HostImage {
   std::vector<ShadeTri> shadeTris;
   std::vector<BvhNode> bvhNodes;
-  std::vector<Wide4> wideNodes;
   std::vector<LeafTri> leafTris;
   std::vector<u4> triVerts;
   std::vector<int32_t> triLight;
@@ -69,7 +67,7 @@ struct HostImage {
   SceneDev view() const {
     SceneDev s{};
     s.shadeTris = shadeTris.data();
-    s.bvhNodes = bvhNodes.data(); s.wideNodes = wideNodes.data(); s.leafTris = leafTris.data(); s.triVerts = triVerts.data();
+    s.bvhNodes = bvhNodes.data(); s.leafTris = leafTris.data(); s.triVerts = triVerts.data();
     s.triLight = triLight.data(); s.vPos = vPos.data(); s.vNormal = vNormal.data();
     s.vTangent = vTangent.data(); s.vUV = vUV.data(); s.meshes = meshes.data(); s.nodes = nodes.data();
     s.materials = materials.data(); s.textures = textures.data(); s.texU8 = texU8.data();
@@ -290,9 +288,6 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
       }
       md.hasAlpha = hasAlpha.empty() ? 0u : hasAlpha[0];
     }
-    md.wideOffset = uint32_t(im.wideNodes.size());
-    buildWide4(im.bvhNodes.data() + md.nodeOffset, md.nNodes, im.wideNodes);
-    md.nWide = uint32_t(im.wideNodes.size()) - md.wideOffset;
     for (uint32_t f = 0; f < m.n_faces; f++) {
       u4 tv; tv.x = m.faces[4 * f]; tv.y = m.faces[4 * f + 1]; tv.z = m.faces[4 * f + 2]; tv.w = m.faces[4 * f + 3];
       im.triVerts.push_back(tv);

@@ -97,11 +97,8 @@ struct MeshDev {
   uint32_t vertOffset;     // into vertex arrays
   uint32_t nTris, nVerts, nNodes;
   uint32_t hasAlpha;       // some triangle of the mesh has an alpha-tested material
-  uint32_t wideOffset;     // into wideNodes (wide_bvh.hpp): record 0 of the mesh stands for the binary root
-  uint32_t nWide, pad0, pad1;
+  uint32_t pad0[4];
 };
-
-struct Wide4;              // wide_bvh.hpp
 
 struct NodeDev {           // core/scene.hpp:11-64
   Xform xf;                // transform (fwd, inv)
@@ -170,7 +167,6 @@ struct LutDev {            // bsdf/luts.hpp:14-24 — float offsets into lutData
 struct SceneDev {
   const ShadeTri* shadeTris;
   const BvhNode* bvhNodes;
-  const Wide4* wideNodes;      // 4-wide re-layout of the same trees, for the lean kernels (wide_bvh.hpp)
   const LeafTri* leafTris;
   const u4* triVerts;          // i0, i1, i2 (mesh-local vertex ids), material
   const int32_t* triLight;

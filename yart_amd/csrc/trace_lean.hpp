@@ -59,9 +59,6 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
   const BvhNode* nodes = sc.bvhNodes;
   const LeafTri* leaves = sc.leafTris;
   bool meshHasAlpha = false;
-  // MODE & TRAV_WIDE (trace_wide_bvh.inc): cursor into the mesh's 4-wide records, their base, the interval end on entering the mesh
-  uint32_t wideCur = 0, wideBase = 0;
-  float tEntry = 0.0f;
   // scene nodes this ray can reach at all: bit n survives if the padded world box of n and of all
   // its ancestors is hit within [0, tMax] (conservative, see traverseScene); used for scenes of fewer than 64 nodes (the all-ones mask marks a new ray)
   unsigned long long cand = 0;
@@ -162,7 +159,6 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
-                  if (MODE & TRAV_WIDE) { wideCur = root.leftFirst & kLinkAlphaBit; wideBase = mesh.wideOffset; tEntry = hit.t; }
                 }
               }
             }
@@ -172,14 +168,10 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
       }
     }
 
-    if constexpr ((MODE & TRAV_WIDE) != 0) {
-#include "trace_wide_bvh.inc"
-    } else {
 #include "trace_lean_bvh2.inc"
-    }
   }
 #undef LEAN_VISIT
-  (void)meshHasAlpha; (void)wideCur; (void)wideBase; (void)tEntry;
+  (void)meshHasAlpha;
 #if defined(YART_COUNT_TRAVERSAL)
   tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
 #else

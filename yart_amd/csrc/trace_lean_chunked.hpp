@@ -50,9 +50,6 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
   const BvhNode* nodes = sc.bvhNodes;
   const LeafTri* leaves = sc.leafTris;
   bool meshHasAlpha = false;
-  // MODE & TRAV_WIDE (trace_wide_bvh.inc): cursor into the mesh's 4-wide records, their base, the interval end on entering the mesh
-  uint32_t wideCur = 0, wideBase = 0;
-  float tEntry = 0.0f;
   // Scene nodes this ray can reach at all, 64 at a time: bit k of `cand` = node candBase + k, set if its
   // padded world box and those of all its ancestors are hit within [0, hit.t] (conservative, see
   // traverseScene). Built by one wave-uniform pass over the chunk's node boxes; a missed node's subtree
@@ -176,7 +173,6 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
-                  if (MODE & TRAV_WIDE) { wideCur = root.leftFirst & kLinkAlphaBit; wideBase = mesh.wideOffset; tEntry = hit.t; }
                 }
               }
             }
@@ -189,14 +185,10 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
     if (__ballot(has && needMask) == 0ull) break;               // a lane moved on to the next node chunk: mask, walk again
     }
 
-    if constexpr ((MODE & TRAV_WIDE) != 0) {
-#include "trace_wide_bvh.inc"
-    } else {
 #include "trace_lean_bvh2.inc"
-    }
   }
 #undef LEAN_VISIT
-  (void)meshHasAlpha; (void)wideCur; (void)wideBase; (void)tEntry;
+  (void)meshHasAlpha;
 #if defined(YART_COUNT_TRAVERSAL)
   tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
 #else

@@ -51,9 +51,6 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
   const BvhNode* nodes = sc.bvhNodes;
   const LeafTri* leaves = sc.leafTris;
   bool meshHasAlpha = false;
-  // MODE & TRAV_WIDE (trace_wide_bvh.inc): cursor into the mesh's 4-wide records, their base, the interval end on entering the mesh
-  uint32_t wideCur = 0, wideBase = 0;
-  float tEntry = 0.0f;
 #if defined(YART_COUNT_TRAVERSAL)
   AlphaCtx actx; actx.sampler = nullptr;     // only its counters are used (YART_COUNT)
 #endif
@@ -146,7 +143,6 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
-                  if (MODE & TRAV_WIDE) { wideCur = root.leftFirst & kLinkAlphaBit; wideBase = mesh.wideOffset; tEntry = hit.t; }
                 }
               }
             }
@@ -156,14 +152,10 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
       }
     }
 
-    if constexpr ((MODE & TRAV_WIDE) != 0) {
-#include "trace_wide_bvh.inc"
-    } else {
 #include "trace_lean_bvh2.inc"
-    }
   }
 #undef LEAN_VISIT
-  (void)meshHasAlpha; (void)wideCur; (void)wideBase; (void)tEntry;
+  (void)meshHasAlpha;
 #if defined(YART_COUNT_TRAVERSAL)
   tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
 #else

@@ -117,10 +117,7 @@ struct HitRec {              // what the walk tracks of cpu/hit.hpp
 //   TRAV_IDENTITY  every scene node's transform chain is the identity (checked at scene build):
 //                  no 4x4 products, the world ray (+0) is used for every node; ~30 VGPRs.
 // Together they bring the closest-hit kernel from 127 to 74 VGPRs, i.e. from 4 to 6 waves/SIMD.
-//   TRAV_WIDE      (with TRAV_FAST, lean kernels only) walk the 4-wide records of wide_bvh.hpp instead of the binary
-//                  tree: same boxes and triangle tests, children visited nearest first over four; alpha subtrees are
-//                  never culled by a hit of this walk (trace_wide_bvh.inc explains why that keeps results exact).
-enum : int { TRAV_GENERAL = 0, TRAV_FAST = 1, TRAV_IDENTITY = 2, TRAV_WIDE = 4 };
+enum : int { TRAV_GENERAL = 0, TRAV_FAST = 1, TRAV_IDENTITY = 2 };
 
 struct AlphaCtx {            // state the stochastic alpha test draws from
   Sampler* sampler;

@@ -309,7 +309,7 @@ struct YartScene {
   SceneDev dev{};
   int numCUs = 256;
   // device copies of the scene image
-  DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<Wide4> wideNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
+  DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32; DevBuf<uint8_t> texQuads;
   DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld; DevBuf<TlasNode> tlas; DevBuf<unsigned long long> nodeBits;
@@ -337,7 +337,7 @@ namespace {
 void uploadScene(YartScene& s) {
   const HostImage& h = s.host;
   s.shadeTris.upload(h.shadeTris);
-  s.bvhNodes.upload(h.bvhNodes); s.wideNodes.upload(h.wideNodes); s.leafTris.upload(h.leafTris); s.triVerts.upload(h.triVerts);
+  s.bvhNodes.upload(h.bvhNodes); s.leafTris.upload(h.leafTris); s.triVerts.upload(h.triVerts);
   s.triLight.upload(h.triLight); s.vPos.upload(h.vPos); s.vNormal.upload(h.vNormal);
   s.vTangent.upload(h.vTangent); s.vUV.upload(h.vUV); s.meshes.upload(h.meshes); s.nodes.upload(h.nodes);
   s.materials.upload(h.materials); s.textures.upload(h.textures); s.texU8.upload(h.texU8);
@@ -361,7 +361,7 @@ void uploadScene(YartScene& s) {
   HIP_CHECK(hipDeviceSynchronize());
   SceneDev d = h.view();       // counts and totals; pointers replaced below
   d.shadeTris = s.shadeTris.p;
-  d.bvhNodes = s.bvhNodes.p; d.wideNodes = s.wideNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
+  d.bvhNodes = s.bvhNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
   d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.texQuads = s.texQuads.p; d.lights = s.lights.p; d.envs = s.envs.p;
@@ -532,9 +532,6 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // trace_lean.hpp keeps one 64-bit node candidate mask per ray and uses the all-ones mask as its "new ray"
   // marker, which a ray that can reach all of exactly 64 nodes would keep: 64 nodes and more go to the chunked form
   const bool chunked = s.host.nodes.size() >= 64;
-  // TRAV_WIDE: the lean kernels walk the 4-wide records (wide_bvh.hpp, trace_wide_bvh.inc)
-  const bool wide = refill && (effFlags & YART_FLAG_WIDE_BVH) != 0;
-  const bool wideE = wide && !(effFlags & 512u), wideS = wide && !(effFlags & 256u);   // (debug: 256 = closest-hit rays only, 512 = shadow rays only)
   // 64 nodes and more: candidate windows from the top-level hierarchy (3; measured the fastest form at every size from 65 to 4252
   // nodes, profiles/r2_many_nodes.txt). Without it (no mesh nodes, more than 16384 nodes = 2 KB of bitset per lane, or debug bit
   // 262144): chunked masks below kLeanWalkNodes nodes, the per-lane walk from there on (debug bit 65536: the walk at any size)
@@ -546,19 +543,17 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
    : nodesForm == 1 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 1> : KERNEL<(M), 1>) : (ident ? KERNEL<(M) | TRAV_IDENTITY, 0> : KERNEL<(M), 0>))
   auto pickExtend = [&]() -> void (*)(WfArgs) {
     if (!refill) return ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
-    if (wideE) return YART_PICK_LEAN(k_wf_extend_lean, TRAV_FAST | TRAV_WIDE);
     return YART_PICK_LEAN(k_wf_extend_lean, TRAV_FAST);
   };
   auto pickShadow = [&]() -> void (*)(WfArgs) {
     if (!refill) return ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>;
-    if (wideS) return YART_PICK_LEAN(k_wf_shadow_lean, TRAV_FAST | TRAV_WIDE);
     return YART_PICK_LEAN(k_wf_shadow_lean, TRAV_FAST);
   };
 #undef YART_PICK_LEAN
   auto kExtendFast = pickExtend();
   auto kShadowFast = pickShadow();
   // debug bit 4096: camera rays (bounce 0) through the one-ray-per-lane kernel, see the launch below (tools/b0_ab.py)
-  const bool cameraOneRay = refill && !wideE && (effFlags & 4096u);
+  const bool cameraOneRay = refill && (effFlags & 4096u);
   auto kExtendCamera = ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
   auto kRetryE = nodesForm == 3 ? k_wf_extend_retry_lean<3> : nodesForm == 2 ? k_wf_extend_retry_lean<2> : nodesForm == 1 ? k_wf_extend_retry_lean<1> : k_wf_extend_retry_lean<0>;
   auto kRetryS = nodesForm == 3 ? k_wf_shadow_retry_lean<3> : nodesForm == 2 ? k_wf_shadow_retry_lean<2> : nodesForm == 1 ? k_wf_shadow_retry_lean<1> : k_wf_shadow_retry_lean<0>;

@@ -239,12 +239,14 @@ int yart_hip_render_waves(YartScene* scene, const YartCameraDesc* cam, const Yar
  * batch; blocks are tile_size, or shard_tile, pixels wide); when a batch ends, the blocks it completed are copied into
  * out_rgba — which then holds, for those pixels, the frame blended up to this wave — and on_tile is called once per
  * block. A non-zero return stops the render after the current batch (YART_ABORTED; out_rgba then holds whatever had
- * been blended). The reference's TileData.rays is not reproduced: rays are counted per wave, not per tile (0 here). */
+ * been blended). YartTileInfo.rays is the reference's TileData.rays: the rays (path segments + unoccluded NEE rays,
+ * mis-integrator.cpp:22, 126) of the block's pixels in this wave — every finished path carries its own count, the blend
+ * kernel sums them per pixel, a small kernel per block; the blocks' counts of a wave sum to that wave's YartStats.rays. */
 typedef struct YartTileInfo {
   uint32_t x, y, width, height;     /* TileData.offset / size */
   uint32_t index, total;            /* TileData.index (1-based count of finished blocks of this wave) / total */
   uint32_t wave, wave_samples, samples_taken, total_samples;   /* samples_taken: after this wave */
-  uint64_t rays;                    /* 0 (see above) */
+  uint64_t rays;                    /* TileData.rays: this block's rays of this wave */
   double ms;                        /* since the wave started */
 } YartTileInfo;
 typedef int (*YartTileCallback)(void* user, const YartTileInfo* tile);
@@ -279,6 +281,13 @@ int yart_hip_multi_rccl_selftest(int device, uint32_t n_floats);
 /* stats: samples / rays / test counters summed over the devices, ms_* the slowest device's, ms_total the call's wall time */
 int yart_hip_multi_render(YartMulti* multi, const YartCameraDesc* cam, const YartRenderParams* params, float* out_rgba,
                           YartStats* stats);
+/* The progressive form of yart_hip_multi_render (what yart_hip_render_waves / _tiles are to yart_hip_render): one wave of the
+ * schedule at a time on all devices, merged, copied to out_rgba and reported through on_wave (Renderer::onRenderWaveComplete
+ * fires whatever the number of workers, tile-renderer.hpp:243-282); with on_tile every block of the frame is reported once per
+ * wave after that wave's merge, in Morton order, with its own ray count. Either callback may be NULL; a non-zero return stops
+ * the render after the current wave (YART_ABORTED). */
+int yart_hip_multi_render_tiles(YartMulti* multi, const YartCameraDesc* cam, const YartRenderParams* params, float* out_rgba,
+                                YartStats* stats, YartWaveCallback on_wave, YartTileCallback on_tile, void* user);
 
 /* Diagnostics (device code paths, used by the parity tests):
  * per-sample radiance (before exposure) of n (x, y, sample) triples -> 3 floats each */

@@ -122,7 +122,7 @@ class HipTileRenderer {
   int tonemapLook = -1;                     // TileRenderer::tonemapper: -1 none (linear HDR), 0 AgX none, 1 golden, 2 punchy
   uint32_t maxBatchPaths = 0;               // YartRenderParams.max_batch_paths: how many tiles finish together (0: a whole wave)
   const DeviceScene* scene = nullptr;
-  const MultiDeviceScene* multiScene = nullptr;   // if set: all its devices render the frame (single wave callbacks only)
+  const MultiDeviceScene* multiScene = nullptr;   // if set: all its devices render every wave of the frame (same callbacks)
   RenderCallback<RenderData> onRenderComplete, onRenderAborted;
   RenderCallback<RenderData, WaveData> onRenderWaveComplete;
   RenderCallback<RenderData, TileData> onRenderTileComplete;
@@ -169,8 +169,8 @@ class HipTileRenderer {
       p.max_batch_paths = maxBatchPaths;
       int rc;
       if (multiScene) {
-        rc = yart_hip_multi_render(multiScene->handle(), &camera_, &p, buffer_.data(), &st);
-        if (rc == YART_OK) { taken_ = samples; rays_ = st.rays; }
+        rc = yart_hip_multi_render_tiles(multiScene->handle(), &camera_, &p, buffer_.data(), &st, &HipTileRenderer::onWave,
+                                         onRenderTileComplete ? &HipTileRenderer::onTile : nullptr, this);
       } else if (onRenderTileComplete) {
         rc = yart_hip_render_tiles(scene->handle(), &camera_, &p, buffer_.data(), &st, &HipTileRenderer::onWave, &HipTileRenderer::onTile, this);
       } else {

@@ -13,7 +13,7 @@
 // does in the reference (cpu/integrator.cpp:6). (INTEGRATION.md "Limits" gives the two accessor lines in the reference
 // that would let the adapter flatten `scene` itself.)
 // Callbacks: onRenderWaveComplete per wave; onRenderTileComplete — if set — per finished tile (finishTile,
-// tile-renderer.hpp:243-262), fed by yart_hip_render_tiles; TileData.rays is 0 (rays are counted per wave).
+// tile-renderer.hpp:243-262), fed by yart_hip_render_tiles; TileData.rays is the block's own ray count of the wave.
 //
 // Compiled against the reference's headers by `make -C oracle ref_hip` (oracle/adapter_main.cpp) and run on the GPU
 // by tests/test_adapter.py. Needs: -I<reference>/src -I<this repo>/include -L<this repo>/yart_amd -lyart_hip.
@@ -86,9 +86,9 @@ public:
       YartStats st{};
       int rc;
       if (multiScene) {
-        // all GPUs of the node: one blocking call; the frame arrives merged (no per-wave callbacks in this form)
-        rc = yart_hip_multi_render(multiScene->handle(), &cam, &p, m_hdr.data(), &st);
-        if (rc == YART_OK) { m_taken = samples; m_rays = st.rays; expose(0, 0, m_buffer.width(), m_buffer.height()); }
+        // all GPUs of the node: every wave rendered by all of them, merged and reported — the same callbacks as with one device
+        rc = yart_hip_multi_render_tiles(multiScene->handle(), &cam, &p, m_hdr.data(), &st, &HipRenderer::onWave,
+                                         onRenderTileComplete ? &HipRenderer::onTile : nullptr, this);
       } else if (onRenderTileComplete) {
         // the wave schedule of tile-renderer.hpp:264-289 with a callback per finished tile (finishTile, :243-262)
         rc = yart_hip_render_tiles(deviceScene->handle(), &cam, &p, m_hdr.data(), &st, &HipRenderer::onWave, &HipRenderer::onTile, this);

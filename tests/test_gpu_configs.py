@@ -201,13 +201,21 @@ def test_tile_callback_reports_every_block_once_per_wave(api):
     first_wave, _ = scene.render(dict(p, stop_sample=8))
     seen, frames = [], []
 
+    tile_rays = []
+
     def on_tile(frame, t):
         seen.append((t["wave"], t["x"], t["y"], t["width"], t["height"], t["index"], t["total"], t["samples_taken"]))
         frames.append(frame[t["y"]:t["y"] + t["height"], t["x"]:t["x"] + t["width"]].copy())
-    waves = []
-    img, st, aborted = scene.render_tiles(p, on_tile, lambda f, info: waves.append(info["wave"]) and None)
+        tile_rays.append((t["wave"], t["rays"]))
+    waves, wave_rays = [], []
+    img, st, aborted = scene.render_tiles(p, on_tile, lambda f, info: (waves.append(info["wave"]), wave_rays.append(info["rays"])) and None)
     assert not aborted and np.array_equal(img.view(np.uint32), plain.view(np.uint32))
     assert waves == [0, 1] and len(seen) == 8
+    # Renderer::TileData.rays (renderer.hpp:40-50): every block reports its own rays of the wave; they sum to the wave's count
+    for w in range(2):
+        mine = [r for ww, r in tile_rays if ww == w]
+        assert all(r > 0 for r in mine) and sum(mine) == wave_rays[w], (w, mine, wave_rays)
+    assert sum(r for _, r in tile_rays) == st["rays"]
     order = [(0, 0), (64, 0), (0, 64), (64, 64)]     # Morton order of the tile coordinates
     for w in range(2):
         got = seen[4 * w:4 * w + 4]
@@ -253,6 +261,21 @@ def test_multi_device_entry_equals_single_device(api):
     assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
     halves = [multi.render(q, rank=r, world_size=2)[0] for r in range(2)]
     assert np.array_equal((halves[0] + halves[1]).view(np.uint32), want2.view(np.uint32))
+    # the progressive form: wave callbacks whatever the number of devices (tile-renderer.hpp:243-282), every block reported once
+    # per wave with its own ray count; the frame after each wave is the single device's after that wave
+    waves, tiles = [], []
+    want_w0, _ = single.render(dict(q, stop_sample=2))
+    got3, st3, ab = multi.render_tiles(q, lambda f, t: tiles.append((t["wave"], t["x"], t["y"], t["rays"], t["index"], t["total"])) and None,
+                                       lambda f, info: waves.append((info["wave"], info["samples_taken"], info["rays"], f.copy())) and None)
+    assert not ab and np.array_equal(got3.view(np.uint32), want2.view(np.uint32))
+    assert [(w, t) for w, t, _, _ in waves] == [(0, 2), (1, 6), (2, 8)]
+    assert np.array_equal(waves[0][3].view(np.uint32), want_w0.view(np.uint32))
+    n_blocks = -(-240 // 16) * -(-136 // 16)
+    for w in range(3):
+        mine = [t for t in tiles if t[0] == w]
+        assert len(mine) == n_blocks and len({(t[1], t[2]) for t in mine}) == n_blocks and [t[4] for t in mine] == list(range(1, n_blocks + 1))
+        assert sum(t[3] for t in mine) == waves[w][2]
+    assert st3["rays"] == sum(w[2] for w in waves)
     multi.close()
     one = api.MultiDeviceScene(s, [0])               # a single device: no merge at all
     got1, _ = one.render(p)

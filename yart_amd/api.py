@@ -182,7 +182,7 @@ EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error
            "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_scene_create_flags", "yart_hip_bvh_build_device", "yart_hip_bvh_build_host", "yart_hip_debug_counters", "yart_hip_debug_shade_regions",
            "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host",
            "yart_hip_multi_create", "yart_hip_multi_load", "yart_hip_multi_destroy", "yart_hip_multi_device_count",
-           "yart_hip_multi_render", "yart_hip_multi_rccl_selftest"]
+           "yart_hip_multi_render", "yart_hip_multi_render_tiles", "yart_hip_multi_rccl_selftest"]
 
 LIB_COUNT_PATH = os.path.join(_HERE, "libyart_hip_count.so")   # instrumented twin (exact test counters)
 _libs = {}
@@ -225,6 +225,8 @@ def lib(instrumented: bool = False):
         L.yart_hip_multi_destroy.restype = None
         L.yart_hip_multi_device_count.argtypes = [C.c_void_p]
         L.yart_hip_multi_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
+        L.yart_hip_multi_render_tiles.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_void_p,
+                                                  C.POINTER(Stats), WAVE_CALLBACK, TILE_CALLBACK, C.c_void_p]
         L.yart_hip_bvh_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.yart_hip_bvh_copy.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _libs[path] = L
@@ -410,7 +412,9 @@ class DeviceScene:
 
         def wave_tr(_user, _stats, wave, wave_samples, taken, total):
             try:
-                return 1 if on_wave(out, dict(wave=wave, wave_samples=wave_samples, samples_taken=taken, total_samples=total)) else 0
+                ws = C.cast(_stats, C.POINTER(Stats)).contents if _stats else None
+                return 1 if on_wave(out, dict(wave=wave, wave_samples=wave_samples, samples_taken=taken, total_samples=total,
+                                              rays=int(ws.rays) if ws is not None else 0)) else 0
             except BaseException as e:
                 errors.append(e)
                 return 1
@@ -502,6 +506,40 @@ class MultiDeviceScene:
             out[...] = accumulated
         _check(self._L.yart_hip_multi_render(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p), C.byref(st)), self._L)
         return out, st.asdict()
+
+    def render_tiles(self, p: dict, on_tile=None, on_wave=None, rank=0, world_size=1, flags=0, accumulated=None):
+        """The progressive form (yart_hip_multi_render_tiles): every wave rendered by all devices, merged, reported through
+        ``on_wave(frame, info)``; with ``on_tile(frame, tile)`` every block of the frame once per wave (Morton order, its own
+        ray count). Returns (frame, stats, aborted)."""
+        cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()
+        out = np.empty((cam.height, cam.width, 4), np.float32)
+        if accumulated is not None:
+            out[...] = accumulated
+        errors = []
+
+        def wave_tr(_user, _stats, wave, wave_samples, taken, total):
+            try:
+                ws = C.cast(_stats, C.POINTER(Stats)).contents if _stats else None
+                return 1 if on_wave(out, dict(wave=wave, wave_samples=wave_samples, samples_taken=taken, total_samples=total,
+                                              rays=int(ws.rays) if ws is not None else 0)) else 0
+            except BaseException as e:
+                errors.append(e)
+                return 1
+
+        def tile_tr(_user, tile):
+            try:
+                return 1 if on_tile(out, tile.contents.asdict()) else 0
+            except BaseException as e:
+                errors.append(e)
+                return 1
+        wcb = WAVE_CALLBACK(wave_tr) if on_wave else WAVE_CALLBACK()
+        tcb = TILE_CALLBACK(tile_tr) if on_tile else TILE_CALLBACK()
+        rc = self._L.yart_hip_multi_render_tiles(self._h, C.byref(cam), C.byref(rp), out.ctypes.data_as(C.c_void_p), C.byref(st), wcb, tcb, None)
+        if errors:
+            raise errors[0]
+        if rc != YART_ABORTED:
+            _check(rc, self._L)
+        return out, st.asdict(), rc == YART_ABORTED
 
     def close(self):
         if self._h:

@@ -81,7 +81,10 @@ __shared__ unsigned long long srLast[4];
 #define SR_MARK(k) ((void)0)
 #endif
 
-enum : uint32_t { WF_SPECULAR = 1u << 8, WF_REGULARIZED = 1u << 9, WF_MISS = 1u << 10, WF_DEPTH_MASK = 0xffu };
+enum : uint32_t { WF_SPECULAR = 1u << 8, WF_REGULARIZED = 1u << 9, WF_MISS = 1u << 10, WF_DEPTH_MASK = 0xffu,
+                  // bits 16..23: unoccluded NEE rays of this path so far (mis-integrator.cpp:126 counts them as rays): with the
+                  // depth they give the path's ray count when it ends (Renderer::TileData.rays, renderer.hpp:40-50)
+                  WF_NEE_SHIFT = 16, WF_NEE_ONE = 1u << 16, WF_NEE_MASK = 0xffu << 16 };
 
 // hit word of the path state: scene node (bits 0..19) | shade class = material index, or kWfClassMiss
 // (bits 20..30) | back side (bit 31). The class is what k_wf_shade buckets its waves by.
@@ -310,7 +313,7 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
     WfPath q;
     q.o = hit.p; q.d = res.wi; q.lastPdf = res.pdf; q.accRoughness = p.accRoughness + res.roughness;
     wfStoreRay(s, i, q);
-    uint32_t fl = (depth + 1) & WF_DEPTH_MASK;
+    uint32_t fl = ((depth + 1) & WF_DEPTH_MASK) | (p.flags & WF_NEE_MASK);
     if (res.scatter & SC_SPECULAR) fl |= WF_SPECULAR;
     if (q.accRoughness > 0.5f) fl |= WF_REGULARIZED;
     p.flags = fl;

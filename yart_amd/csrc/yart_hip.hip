@@ -91,7 +91,7 @@ struct MegaArgs {
   RenderConst rc;
   const uint32_t* pixels;      // packed x | y << 16, tile-major order
   uint32_t nPixels, spp, sampleOffset, pad;
-  float* L;                    // 3 floats per (pixel, sample)
+  f4* L;                    // 3 floats per (pixel, sample)
   uint32_t* cursor;
   unsigned long long* rays;
   uint64_t* spill;             // kSpillDepth entries per launched thread, lane-interleaved
@@ -119,8 +119,9 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(MegaArgs a) {
     if (w < total) {
       const uint32_t pi = w / a.spp, s = w - pi * a.spp;
       const uint32_t pk = a.pixels[pi];
+      const uint32_t before = rays;
       f3 L = samplePixel(cx, a.cam, pk & 0xffffu, pk >> 16, s + a.sampleOffset, rays);
-      a.L[size_t(w) * 3 + 0] = L.x; a.L[size_t(w) * 3 + 1] = L.y; a.L[size_t(w) * 3 + 2] = L.z;
+      a.L[w] = mk4(L.x, L.y, L.z, asF(rays - before));
     }
   }
   // one atomic per wave
@@ -138,7 +139,8 @@ __global__ void __launch_bounds__(kBlock) k_render_mega(MegaArgs a) {
 }
 
 struct GmonArgs {
-  const float* L;
+  const f4* L;                 // per (pixel, sample): radiance.xyz, ray count
+  uint32_t* pixRays;           // per pixel of the batch: the wave's ray count of that pixel (nullptr: not wanted)
   const uint32_t* pixels;
   uint32_t nPixels, spp, width;
   int kind;                    // EstimatorKind
@@ -159,28 +161,38 @@ __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
   const uint32_t pi = blockIdx.x * kGmonPixPerBlock + lp;
   const bool valid = pi < a.nPixels;
   const int m = estimatorBuckets(a.kind, int32_t(a.spp));
+  __shared__ uint32_t sRays[kGmonPixPerBlock][kGmonMax];
   if (valid && int(sub) < m) {
-    f3 acc = mk3(0); uint32_t cnt = 0;
-    const float* p = a.L + size_t(pi) * a.spp * 3;
+    f3 acc = mk3(0); uint32_t cnt = 0, rays = 0;
+    const f4* p = a.L + size_t(pi) * a.spp;
     // bucket k mod m, increasing k; four samples' loads in flight, accumulated in order
     const uint32_t um = uint32_t(m);
     uint32_t s = sub;
     for (; s + 3u * um < a.spp; s += 4u * um) {
-      f3 v[4];
-      for (uint32_t j = 0; j < 4u; j++) { const float* q = p + size_t(s + j * um) * 3; v[j] = mk3(q[0], q[1], q[2]); }
+      f4 v[4];
+      for (uint32_t j = 0; j < 4u; j++) v[j] = p[s + j * um];
       for (uint32_t j = 0; j < 4u; j++) {
-        const f3 w = v[j] * a.exposureScale;
+        const f3 w = mk3(v[j].x, v[j].y, v[j].z) * a.exposureScale;
         if (estimatorAccepts(a.kind, w)) { acc += w; cnt++; }
+        rays += __builtin_bit_cast(uint32_t, v[j].w);
       }
     }
     for (; s < a.spp; s += um) {
-      f3 v = mk3(p[s * 3], p[s * 3 + 1], p[s * 3 + 2]) * a.exposureScale;
+      const f4 q = p[s];
+      f3 v = mk3(q.x, q.y, q.z) * a.exposureScale;
       if (estimatorAccepts(a.kind, v)) { acc += v; cnt++; }
+      rays += __builtin_bit_cast(uint32_t, q.w);
     }
     sAcc[lp][sub] = acc;
     sCnt[lp][sub] = cnt;
+    sRays[lp][sub] = rays;
   }
   __syncthreads();
+  if (valid && sub == 0 && a.pixRays != nullptr) {
+    uint32_t r = 0;
+    for (int b = 0; b < m; b++) r += sRays[lp][b];
+    a.pixRays[pi] = r;
+  }
   if (valid && sub == 0) {
     f3 v = estimatorFinish(a.kind, sAcc[lp], sCnt[lp], m, a.spp);
     const uint32_t pk = a.pixels[pi];
@@ -191,6 +203,18 @@ __global__ void __launch_bounds__(kBlock) k_gmon_blend(GmonArgs a) {
     o[2] = o[2] * a.wCurrent + v.z * a.wWave;
     o[3] = o[3] * a.wCurrent + 1.0f * a.wWave;
   }
+}
+
+// Renderer::TileData.rays (renderer.hpp:40-50; tile-renderer.hpp:183 passes the tile integrator's ray count): per pixel block of
+// this rank the sum of its pixels' ray counts of the wave (k_gmon_blend's pixRays); one wave per block
+__global__ void __launch_bounds__(64) k_tile_rays(const uint32_t* pixRays, const uint32_t* tileStart, const uint32_t* tileCount,
+                                                  uint32_t firstTile, uint32_t nTiles, unsigned long long* out) {
+  const uint32_t t = firstTile + blockIdx.x;
+  if (blockIdx.x >= nTiles) return;
+  unsigned long long r = 0;
+  for (uint32_t i = threadIdx.x; i < tileCount[t]; i += 64u) r += pixRays[tileStart[t] + i];
+  for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o);
+  if (threadIdx.x == 0) out[t] = r;
 }
 
 // AgX tonemap of an RGBA32F frame (alpha kept as 1, tile-renderer.hpp:234-237) and the 8-bit
@@ -316,7 +340,9 @@ struct YartScene {
   DevBuf<uint32_t> infiniteLights, areaLights; DevBuf<float> areaPowerCdf; DevBuf<float> lut;
   DevBuf<uint8_t> matClass;                // host_scene.hpp::lobeClass per material
   // render scratch (grown on demand, reused across calls)
-  DevBuf<uint32_t> pixels; DevBuf<float> L; DevBuf<uint32_t> cursor; DevBuf<unsigned long long> counters;
+  DevBuf<uint32_t> pixels; DevBuf<f4> L; DevBuf<uint32_t> cursor; DevBuf<unsigned long long> counters;
+  DevBuf<uint32_t> pixRays, tileStart, tileCount; DevBuf<unsigned long long> tileRays;   // per-block ray counts (tile callbacks only)
+  std::vector<unsigned long long> tileRaysHost;
   DevBuf<uint64_t> spill; DevBuf<float> hdr; DevBuf<uint32_t> probeIn; DevBuf<float> probeOut;
   DevBuf<f4> wf[9];                        // wavefront path state (wavefront.hpp::WfState)
   DevBuf<f4> wfTail[2][9];                 // compacted states of the late bounces (1/2 and 1/4 of the batch)
@@ -439,6 +465,11 @@ void buildPixelList(YartScene& s, uint32_t W, uint32_t H, uint32_t tile, uint32_
   if (s.pixW == W && s.pixH == H && s.pixTile == tile && s.pixRank == rank && s.pixWorld == world) return;
   s.pixelsHost = makePixelList(W, H, tile, rank, world, &s.tiles);
   s.pixels.upload(s.pixelsHost);
+  {
+    std::vector<uint32_t> start, count;
+    for (const YartScene::TileRec& t : s.tiles) { start.push_back(t.start); count.push_back(t.count); }
+    s.tileStart.upload(start); s.tileCount.upload(count);
+  }
   s.pixW = W; s.pixH = H; s.pixTile = tile; s.pixRank = rank; s.pixWorld = world;
 }
 
@@ -588,20 +619,20 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const uint32_t waveCap = std::max(std::min(p.first_wave_samples, p.samples), maxWave);
   size_t freeB = 0, totalB = 0;
   HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
-  uint64_t held = uint64_t(s.L.n) * 4 + (uint64_t(s.qA.n) + s.qB.n + s.qS.n + s.qR.n) * 4;
+  uint64_t held = uint64_t(s.L.n) * 16 + (uint64_t(s.qA.n) + s.qB.n + s.qS.n + s.qR.n) * 4;
   for (auto& b : s.wf) held += uint64_t(b.n) * 16;
   for (auto& t : s.wfTail) for (auto& b : t) held += uint64_t(b.n) * 16;
   held += (uint64_t(s.wfTailMap[0].n) + s.wfTailMap[1].n) * 4;
   held += uint64_t(s.smpEntries.n) * 8;      // the sampler tables of the previous render stay allocated
   // with compaction: two tail states of 1/2 and 1/4 of the batch (9 x 16 B + a slot map word each) = 111 B per path
   const bool compact = !mega && !(p.flags & YART_FLAG_NO_COMPACTION);
-  const uint64_t perPath = mega ? 12 : compact ? 283 : 172;
+  const uint64_t perPath = mega ? 16 : compact ? 287 : 176;
   uint64_t maxPaths = std::max<uint64_t>((uint64_t(freeB) + held) * (compact ? 6 : 5) / 10 / perPath, 1u << 20);
   if (!mega) maxPaths = std::min<uint64_t>(maxPaths, kWfMaxPaths);
   maxPaths = std::min<uint64_t>(maxPaths, (1ull << 31) - 64);
   if (p.max_batch_paths) maxPaths = std::min<uint64_t>(maxPaths, p.max_batch_paths);
   uint32_t chunk = uint32_t(std::min<uint64_t>(nPix ? nPix : 1, std::max<uint64_t>(maxPaths / waveCap, 1)));
-  s.L.ensure(size_t(chunk) * waveCap * 3);
+  s.L.ensure(size_t(chunk) * waveCap);
   if (!mega) {
     const size_t np = size_t(chunk) * waveCap;
     for (auto& b : s.wf) b.ensure(np);
@@ -653,6 +684,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     if (!inRange && takenBefore < startSample && takenAfter > startSample) throw std::invalid_argument("start_sample is not a wave boundary");
     if (inRange && takenAfter > stopSample) throw std::invalid_argument("stop_sample is not a wave boundary");
     if (inRange) { waves++; renderedSamples += waveSamples; }
+    size_t tileDone = 0;                     // blocks of this wave whose ray counts have been summed (tile callbacks only)
     for (uint32_t c0 = 0; inRange && !aborted && c0 < nPix; c0 += chunk) {
       const uint32_t n = std::min(chunk, nPix - c0);
       if (mega) {
@@ -750,6 +782,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         }
       }
       GmonArgs g{};
+      if (hook && *hook) { s.pixRays.ensure(std::max<uint32_t>(nPix, 1u)); g.pixRays = s.pixRays.p + c0; }
       g.L = s.L.p; g.pixels = s.pixels.p + c0; g.nPixels = n; g.spp = uint32_t(waveSamples); g.width = W;
       g.exposureScale = cam.exposureScale; g.wCurrent = wCurrent; g.wWave = wWave; g.hdr = dOut;
       g.kind = int(p.estimator);
@@ -760,6 +793,19 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       HIP_CHECK(hipStreamSynchronize(stream));
       tMega.resolve(); tExtend.resolve(); tShade.resolve(); tConnect.resolve(); tGmon.resolve(); tLean.resolve(); tShadeK.resolve(); tShadowLean.resolve();
       if (hook && *hook) {
+        // ray counts of the blocks this batch completed (their pixels' counts of this wave are all in pixRays now)
+        size_t done = tileDone;
+        while (done < s.tiles.size() && s.tiles[done].start + s.tiles[done].count <= c0 + n) done++;
+        if (done > tileDone) {
+          s.tileRays.ensure(s.tiles.size()); s.tileRaysHost.resize(s.tiles.size());
+          hipLaunchKernelGGL(k_tile_rays, dim3(uint32_t(done - tileDone)), dim3(64), 0, stream, s.pixRays.p, s.tileStart.p, s.tileCount.p,
+                             uint32_t(tileDone), uint32_t(done - tileDone), s.tileRays.p);
+          HIP_CHECK(hipGetLastError());
+          HIP_CHECK(hipMemcpyAsync(s.tileRaysHost.data() + tileDone, s.tileRays.p + tileDone, (done - tileDone) * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, stream));
+          HIP_CHECK(hipStreamSynchronize(stream));
+          tileDone = done;
+        }
         const BatchInfo bi{c0, n, uint32_t(currentWave), uint32_t(waveSamples), uint32_t(takenAfter), p.samples};
         if ((*hook)(bi)) aborted = true;
       }
@@ -970,6 +1016,7 @@ static int renderProgressive(YartScene* scene, const YartCameraDesc* cam, const 
             ti.x = t.x; ti.y = t.y; ti.width = t.w; ti.height = t.h;
             ti.index = uint32_t(nextTile); ti.total = uint32_t(tiles.size());
             ti.wave = b.wave; ti.wave_samples = b.waveSamples; ti.samples_taken = b.samplesTaken; ti.total_samples = b.totalSamples;
+            ti.rays = nextTile - 1 < scene->tileRaysHost.size() ? scene->tileRaysHost[nextTile - 1] : 0;
             ti.ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - tw).count();
             if (on_tile(user, &ti) != 0) stopNow = true;
           }
@@ -1073,6 +1120,17 @@ int yart_hip_multi_render(YartMulti* multi, const YartCameraDesc* cam, const Yar
     validate(cam, params);
     renderMulti(*multi, *cam, *params, out_rgba, stats);
   });
+}
+
+int yart_hip_multi_render_tiles(YartMulti* multi, const YartCameraDesc* cam, const YartRenderParams* params, float* out_rgba,
+                                YartStats* stats, YartWaveCallback on_wave, YartTileCallback on_tile, void* user) {
+  bool aborted = false;
+  const int rc = guarded([&] {
+    require(multi && out_rgba, "multi / output pointer is null");
+    validate(cam, params);
+    aborted = renderMultiProgressive(*multi, *cam, *params, out_rgba, stats, on_wave, on_tile, user) == YART_ABORTED;
+  });
+  return rc == YART_OK && aborted ? YART_ABORTED : rc;
 }
 
 int yart_hip_probe_samples(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,

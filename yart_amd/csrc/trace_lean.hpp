@@ -37,8 +37,9 @@ constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;   // leave the inner loo
 struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general variant only (alpha tests)
 
 // Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)
-// Commit(slot, hit, didHit, attenuation, samplerDim); Retry(pred, slot) appends to the retry queue
-// (wave-wide call). MODE without TRAV_FAST = the general walk (alpha tests inline, no hand-over).
+// Commit(slot, hit, didHit, attenuation, samplerDim): called for all lanes that finished since the last refill, together;
+// Retry(pred, slot) appends to the retry queue (wave-wide call). MODE without TRAV_FAST = the general walk (alpha tests
+// inline, no hand-over).
 template <bool NEE, int MODE, class Fetch, class Commit, class Retry>
 __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk, const uint32_t* queue,
                                           uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
@@ -50,7 +51,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
   const unsigned long long laneLt = (1ull << lane) - 1ull;
   const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
   const float tMin = 0.001f;
-  bool has = false, inMesh = false, exhausted = false, firstFill = true, pendingRetry = false;
+  bool has = false, inMesh = false, exhausted = false, firstFill = true, pendingRetry = false, done = false;
   bool didHit = false, meshDidHit = false, rayIsWorld = false;
   uint32_t slot = 0, nodeI = 0, leftFirst = 0, span = 0, stackIdx = 0;
   float d = 0.0f;
@@ -74,6 +75,9 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
     if (has) WF_PHASE(tally, 5);                               // outer rounds / lanes holding a ray
     const unsigned long long idle = __ballot(!has);
     const uint32_t nIdle = uint32_t(__popcll(idle));
+    // results of the rays that finished since the last refill are committed together, just before their lanes take new
+    // rays (>= kLeanRefill lanes: what a commit loads / stores is issued for most of the wave at once, not lane by lane)
+    if ((nIdle >= kLeanRefill || exhausted) && done) { commit(slot, hit, didHit, attenuation, smp.dim); done = false; }
     if (nIdle == 64u && exhausted) break;
     if (!exhausted && nIdle >= kLeanRefill) {
       uint32_t base;
@@ -125,7 +129,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
         WF_PHASE(tally, 3);                                     // walk steps
         const unsigned long long rest = nodeI < 64u ? (cand >> nodeI) : 0ull;
         if (rest == 0ull) {                                     // testNode of the root has returned
-          commit(slot, hit, didHit, attenuation, smp.dim);
+          done = true;                                          // (committed at the next refill)
           has = false;
         } else {
           nodeI += uint32_t(__builtin_ctzll(rest));             // next node the ray can reach

@@ -42,7 +42,7 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
   const unsigned long long laneLt = (1ull << lane) - 1ull;
   const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
   const float tMin = 0.001f;
-  bool has = false, inMesh = false, exhausted = false, firstFill = true, pendingRetry = false;
+  bool has = false, inMesh = false, exhausted = false, firstFill = true, pendingRetry = false, done = false;
   bool didHit = false, meshDidHit = false, rayIsWorld = false;
   uint32_t slot = 0, nodeI = 0, leftFirst = 0, span = 0, stackIdx = 0;
   float d = 0.0f;
@@ -63,6 +63,9 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
     if (has) WF_PHASE(tally, 5);                               // outer rounds / lanes holding a ray
     const unsigned long long idle = __ballot(!has);
     const uint32_t nIdle = uint32_t(__popcll(idle));
+    // results of the rays that finished since the last refill are committed together, just before their lanes take new
+    // rays (>= kLeanRefill lanes: what a commit loads / stores is issued for most of the wave at once, not lane by lane)
+    if ((nIdle >= kLeanRefill || exhausted) && done) { commit(slot, hit, didHit, attenuation, smp.dim); done = false; }
     if (nIdle == 64u && exhausted) break;
     if (!exhausted && nIdle >= kLeanRefill) {
       uint32_t base;
@@ -97,7 +100,7 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
       while (has && !inMesh) {                                  // (lanes leave this loop one by one)
         WF_PHASE(tally, 3);                                     // walk steps
         if (nodeI >= sc.nNodes) {                               // testNode of the root has returned
-          commit(slot, hit, didHit, attenuation, smp.dim);
+          done = true;                                          // (committed at the next refill)
           has = false;
           break;
         }

@@ -3,12 +3,13 @@
 //
 //   generate  camera ray, path state                       (ray-integrator.cpp:11-18)
 //   extend    closest-hit traversal of every live path     (testNode, :20-54)
-//   shade     miss / emission / BSDF sample / NEE set-up / throughput update
-//             (mis-integrator.cpp:27-95, 111-124)
-//   shadow    any-hit traversal of the shadow rays -> {attenuation, occluded}     (:135-148)
-//   post      NEE contribution (:125-133) and, for the paths that cast a shadow ray, the Russian
-//             roulette + next-bounce decision (:96-102) — after the shadow traversal, which may
-//             consume sampler dimensions first; the other paths take it at the end of `shade`.
+//   shade     miss / emission / BSDF sample / NEE set-up / throughput update; Russian roulette of the paths that cast no
+//             shadow ray (mis-integrator.cpp:27-102, 111-124)
+//   shadow    any-hit traversal of the shadow rays (:135-148); the NEE contribution (:125-133) is added to the path's
+//             radiance where the traversal result is committed (wfShadowCommit) — no pass of its own
+//   roulette  for the paths that cast a shadow ray: the Russian roulette + next-bounce decision (:96-102) AFTER the shadow
+//             traversal, which may consume sampler dimensions first. Needed from the second bounce on only (the roulette
+//             starts at depth 2): 16-48 bytes per path instead of the 120 a full post pass moved
 //
 // Path state lives in HBM as float4-packed SoA arrays indexed by path slot, so that a
 // wave's 64 lanes read 1 KiB contiguous per field group. Every arithmetic expression is
@@ -20,10 +21,10 @@ namespace yart_hip {
 
 struct WfState {
   // ray0 = {o.xyz, d.x}  ray1 = {d.yz, lastPdf, accRoughness}
-  // thr0 = {att.xyz, L.x} thr1 = {L.yz, flags(u32), dim(u32)}
+  // thr = {att.xyz, dim(u32)}   acc = {L.xyz, flags(u32)}
   // hit0 = {t, u, v, tri(u32)}  hit1 = {hit word (wfHitWord), morton.lo, morton.hi, sampler-table column (u32)}
-  // sh0 = {to.xyz, -}  sh1 = {attPre.xyz, denom}  sh2 = {Lif.xyz, cosTerm}   (k_wf_post reads sh1, sh2 only)
-  f4 *ray0, *ray1, *thr0, *thr1, *hit0, *hit1, *sh0, *sh1, *sh2;
+  // sh0 = {to.xyz, -}  sh1 = {attPre.xyz, denom}  sh2 = {Lif.xyz, cosTerm}   (read where a shadow ray's result is committed)
+  f4 *ray0, *ray1, *thr, *acc, *hit0, *hit1, *sh0, *sh1, *sh2;
 };
 // exact test counters of the instrumented build (libyart_hip_count.so); empty otherwise
 struct WfTally {
@@ -84,7 +85,11 @@ __shared__ unsigned long long srLast[4];
 enum : uint32_t { WF_SPECULAR = 1u << 8, WF_REGULARIZED = 1u << 9, WF_MISS = 1u << 10, WF_DEPTH_MASK = 0xffu,
                   // bits 16..23: unoccluded NEE rays of this path so far (mis-integrator.cpp:126 counts them as rays): with the
                   // depth they give the path's ray count when it ends (Renderer::TileData.rays, renderer.hpp:40-50)
-                  WF_NEE_SHIFT = 16, WF_NEE_ONE = 1u << 16, WF_NEE_MASK = 0xffu << 16 };
+                  WF_NEE_SHIFT = 16, WF_NEE_ONE = 1u << 16, WF_NEE_MASK = 0xffu << 16,
+                  // set by shade for a path with a shadow ray in flight: FINAL = the bounce budget is used up, whoever commits the
+                  // shadow ray's result writes the path's radiance out; ATT_NAN = the throughput before the bounce is not finite,
+                  // so that even an occluded light sample changes the radiance (L += attenuation * 0, mis-integrator.cpp:80)
+                  WF_FINAL = 1u << 11, WF_ATT_NAN = 1u << 12 };
 
 // hit word of the path state: scene node (bits 0..19) | shade class = material index, or kWfClassMiss
 // (bits 20..30) | back side (bit 31). The class is what k_wf_shade buckets its waves by.
@@ -123,10 +128,10 @@ struct WfPath {             // register image of one path
   Sampler smp;
 };
 YART_HD WfPath wfLoad(const WfState& s, uint32_t i) {
-  const f4 r0 = wfLd(s.ray0 + i), r1 = wfLd(s.ray1 + i), t0 = wfLd(s.thr0 + i), t1 = wfLd(s.thr1 + i), h1 = wfLd(s.hit1 + i);
+  const f4 r0 = wfLd(s.ray0 + i), r1 = wfLd(s.ray1 + i), t = wfLd(s.thr + i), a = wfLd(s.acc + i), h1 = wfLd(s.hit1 + i);
   WfPath p;
   p.o = mk3(r0.x, r0.y, r0.z); p.d = mk3(r0.w, r1.x, r1.y); p.lastPdf = r1.z; p.accRoughness = r1.w;
-  p.att = mk3(t0.x, t0.y, t0.z); p.L = mk3(t0.w, t1.x, t1.y); p.flags = asU(t1.z); p.smp.dim = asU(t1.w);
+  p.att = mk3(t.x, t.y, t.z); p.smp.dim = asU(t.w); p.L = mk3(a.x, a.y, a.z); p.flags = asU(a.w);
   p.smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32); p.smp.pix = asU(h1.w); p.slot = i;
   return p;
 }
@@ -135,9 +140,10 @@ YART_HD void wfStoreRay(const WfState& s, uint32_t i, const WfPath& p) {
   wfSt(s.ray1 + i, mk4(p.d.y, p.d.z, p.lastPdf, p.accRoughness));
 }
 YART_HD void wfStoreThr(const WfState& s, uint32_t i, const WfPath& p) {
-  wfSt(s.thr0 + i, mk4(p.att.x, p.att.y, p.att.z, p.L.x));
-  wfSt(s.thr1 + i, mk4(p.L.y, p.L.z, asF(p.flags), asF(p.smp.dim)));
+  wfSt(s.thr + i, mk4(p.att.x, p.att.y, p.att.z, asF(p.smp.dim)));
+  wfSt(s.acc + i, mk4(p.L.x, p.L.y, p.L.z, asF(p.flags)));
 }
+YART_HD uint32_t wfPathRays(uint32_t flags) { return (flags & WF_DEPTH_MASK) + ((flags & WF_NEE_MASK) >> WF_NEE_SHIFT); }
 
 // Russian roulette and loop condition (mis-integrator.cpp:96-102 + the while at :21).
 // Returns true if the path continues to the next bounce.
@@ -166,15 +172,56 @@ YART_HD void wfGenerate(const RenderConst& rc, const uint32_t* sobol, const Came
   s.hit1[i] = mk4(0.0f, asF(uint32_t(p.smp.morton)), asF(uint32_t(p.smp.morton >> 32)), asF(pix));
 }
 
-// extend: closest hit; only the sampler dimension can change (alpha tests)
-// extend, general variant: every triangle kind, any node transforms
+// The Russian roulette + next-bounce decision of a path that cast a shadow ray (mis-integrator.cpp:96-102), after the shadow
+// traversal (whose alpha tests may have drawn sampler dimensions: thr.w is current). `depth` = bounces done, uniform over
+// the launch and >= 2 here. Returns true if the path continues; otherwise its radiance and ray count go to `out`.
+YART_HD bool wfRouletteAfterShadow(const RenderConst& rc, const WfState& s, uint32_t slot, uint32_t depth, f4* out, const uint32_t* slotMap) {
+  const f4 t = wfLd(s.thr + slot);
+  WfPath p;
+  p.att = mk3(t.x, t.y, t.z);
+  if (!(maxComponent(p.att) < 1.0f)) return true;              // no draw (wfRoulette), and depth < maxDepth or the path were FINAL
+  const f4 h1 = wfLd(s.hit1 + slot);
+  p.smp.dim = asU(t.w); p.smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32); p.smp.pix = asU(h1.w);
+  p.flags = depth;
+  if (wfRoulette(rc, p)) {
+    wfSt(s.thr + slot, mk4(p.att.x, p.att.y, p.att.z, asF(p.smp.dim)));
+    return true;
+  }
+  const f4 a = wfLd(s.acc + slot);
+  wfSt(out + (slotMap ? slotMap[slot] : slot), mk4(a.x, a.y, a.z, asF(wfPathRays(asU(a.w)))));
+  return false;
+}
+
+// What a finished shadow ray leaves behind (mis-integrator.cpp:125-133 + the caller's `L += attenuation * Ld`, :80):
+// unoccluded -> L += attPre * (Lif * attOcc * cos / denom), one more ray; occluded -> L += attPre * 0, which only a non-finite
+// throughput makes visible (WF_ATT_NAN); a path whose bounce budget is used up (WF_FINAL) is written out here.
+// Returns 1 if the ray counts (unoccluded).
+YART_HD uint32_t wfShadowCommit(const WfState& s, uint32_t slot, bool occluded, f3 attOcc, f4* out, const uint32_t* slotMap) {
+  f4 a = wfLd(s.acc + slot);
+  uint32_t flags = asU(a.w);
+  if (occluded && !(flags & (WF_FINAL | WF_ATT_NAN))) return 0u;
+  f3 L = mk3(a.x, a.y, a.z);
+  if (!occluded) {
+    const f4 s1 = wfLd(s.sh1 + slot), s2 = wfLd(s.sh2 + slot);
+    L += mk3(s1.x, s1.y, s1.z) * (mk3(s2.x, s2.y, s2.z) * attOcc * s2.w / s1.w);
+    flags += WF_NEE_ONE;
+  } else if (flags & WF_ATT_NAN) {
+    const f4 s1 = wfLd(s.sh1 + slot);
+    L += mk3(s1.x, s1.y, s1.z) * mk3(0.0f);
+  }
+  if (flags & WF_FINAL) wfSt(out + (slotMap ? slotMap[slot] : slot), mk4(L.x, L.y, L.z, asF(wfPathRays(flags))));
+  else wfSt(s.acc + slot, mk4(L.x, L.y, L.z, asF(flags)));
+  return occluded ? 0u : 1u;
+}
+
+// extend, general variant (one ray per lane): every triangle kind, any node transforms; only the sampler dimension can
+// change (alpha tests)
 YART_HD void wfExtend(const SceneDev& sc, const RenderConst& rc, const TravStack& stk, const WfState& s,
                       uint32_t i, WfTally& tally) {
   const f4 r0 = s.ray0[i], r1 = s.ray1[i];
-  f4 t1 = s.thr1[i];
   f4 h1 = s.hit1[i];
   Sampler smp;
-  smp.dim = asU(t1.w);
+  smp.dim = asU(s.thr[i].w);
   smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32); smp.pix = asU(h1.w);
   const uint32_t dim0 = smp.dim;
   HitRec hr;
@@ -186,7 +233,7 @@ YART_HD void wfExtend(const SceneDev& sc, const RenderConst& rc, const TravStack
   s.hit0[i] = mk4(hit ? hr.t : -1.0f, hr.u, hr.v, asF(hr.tri));
   h1.x = asF(wfHitWord(hr, hit));
   s.hit1[i] = h1;
-  if (smp.dim != dim0) { t1.w = asF(smp.dim); s.thr1[i] = t1; }
+  if (smp.dim != dim0) s.thr[i].w = asF(smp.dim);
 }
 
 // extend, fast variant (traverse.hpp TRAV_FAST [| TRAV_IDENTITY]): no sampler state, no alpha
@@ -207,11 +254,11 @@ YART_HD bool wfExtendFast(const SceneDev& sc, const TravStack& stk, const WfStat
   return true;
 }
 
-// shadow ray of the path in slot i (mis-integrator.cpp:137-146) -> hit0 = {attenuation, occluded};
-// the NEE contribution and the roulette are k_wf_post's. Fast variant: same contract as wfExtendFast.
+// shadow ray of the path in slot i, one ray per lane (mis-integrator.cpp:137-146); the result is committed here
+// (wfShadowCommit). Fast variant: same contract as wfExtendFast. `rays` counts the unoccluded ones.
 template <int MODE>
 YART_HD bool wfShadow(const SceneDev& sc, const RenderConst& rc, const TravStack& stk, const WfState& s,
-                      uint32_t i, WfTally& tally) {
+                      uint32_t i, WfTally& tally, f4* out, const uint32_t* slotMap, uint32_t& rays) {
   const f4 r0 = s.ray0[i], s0 = s.sh0[i];
   const f3 from = mk3(r0.x, r0.y, r0.z), to = mk3(s0.x, s0.y, s0.z);
   const f3 dir = normalized(to - from);                     // :140
@@ -224,14 +271,14 @@ YART_HD bool wfShadow(const SceneDev& sc, const RenderConst& rc, const TravStack
   AlphaCtx ac; ac.sampler = &smp; ac.cfg = rc.sampler;
   if (!(MODE & TRAV_FAST)) {
     const f4 h1 = s.hit1[i];
-    smp.dim = dim0 = asU(s.thr1[i].w);
+    smp.dim = dim0 = asU(s.thr[i].w);
     smp.morton = uint64_t(asU(h1.y)) | (uint64_t(asU(h1.z)) << 32); smp.pix = asU(h1.w);
   }
   const bool occluded = traverseScene<true, MODE>(sc, from, dir, 0.001f, hr, attOcc, stk, ac);
   WF_TALLY_TRAV(tally, ac);
   if ((MODE & TRAV_FAST) && ac.deferred) return false;
-  s.hit0[i] = mk4(attOcc.x, attOcc.y, attOcc.z, occluded ? 1.0f : 0.0f);
-  if (!(MODE & TRAV_FAST) && smp.dim != dim0) s.thr1[i].w = asF(smp.dim);
+  if (!(MODE & TRAV_FAST) && smp.dim != dim0) s.thr[i].w = asF(smp.dim);
+  rays += wfShadowCommit(s, i, occluded, attOcc, out, slotMap);
   return true;
 }
 
@@ -350,6 +397,13 @@ YART_HD WfShadeResult wfShade(const SceneDev& sc, const RenderConst& rc, const u
         wfSt(s.sh1 + i, mk4(p.att.x, p.att.y, p.att.z, pdfBSDF + pdfLight));
         wfSt(s.sh2 + i, mk4(Lif.x, Lif.y, Lif.z, absDot(ls.wi, hit.n)));
         shadow = true;
+        // for whoever commits the shadow ray's result (wfShadowCommit): the bounce budget is used up -> the path's radiance is
+        // written out there; a throughput that is not finite makes even an occluded sample count (attenuation * 0 = NaN)
+        if ((p.flags & WF_DEPTH_MASK) >= rc.maxDepth) p.flags |= WF_FINAL;
+        {
+          const f3 z = p.att * mk3(0.0f);
+          if (!(z.x == 0.0f && z.y == 0.0f && z.z == 0.0f)) p.flags |= WF_ATT_NAN;
+        }
         SR_MARK(10);                                            // BSDF pdf, shadow-ray set-up stored
       }
     }

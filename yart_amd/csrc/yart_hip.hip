@@ -700,7 +700,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       } else {
         WfArgs a{};
         a.sc = s.dev; a.cam = cam; a.rc = rcw; a.pixBase = c0;
-        a.st.ray0 = s.wf[0].p; a.st.ray1 = s.wf[1].p; a.st.thr0 = s.wf[2].p; a.st.thr1 = s.wf[3].p;
+        a.st.ray0 = s.wf[0].p; a.st.ray1 = s.wf[1].p; a.st.thr = s.wf[2].p; a.st.acc = s.wf[3].p;
         a.st.hit0 = s.wf[4].p; a.st.hit1 = s.wf[5].p; a.st.sh0 = s.wf[6].p; a.st.sh1 = s.wf[7].p; a.st.sh2 = s.wf[8].p;
         a.qA = s.qA.p; a.qB = s.qB.p; a.qS = s.qS.p; a.qR = s.qR.p; a.counters = s.wfCounters.p;
         a.pixels = s.pixels.p + c0; a.nPaths = n * uint32_t(waveSamples); a.spp = uint32_t(waveSamples);
@@ -726,6 +726,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         HIP_CHECK(hipGetLastError());
         tShade.end(stream);
         for (uint32_t bounce = 0; bounce < rc.maxDepth; bounce++) {
+          a.bounce = bounce;
           tExtend.begin(stream);
           if (general) {
             hipLaunchKernelGGL(k_wf_extend<false>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
@@ -765,10 +766,14 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           }
           HIP_CHECK(hipGetLastError());
           tConnect.end(stream);
-          tShade.begin(stream);
-          hipLaunchKernelGGL(k_wf_post, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
-          HIP_CHECK(hipGetLastError());
-          tShade.end(stream);
+          // Russian roulette of the paths that cast a shadow ray: from the second bounce on (at depth 1 none applies: k_wf_shade
+          // queued them itself), not after the last one (their radiance has been written out by the shadow kernels)
+          if (bounce >= 1 && bounce + 1 < rc.maxDepth) {
+            tShade.begin(stream);
+            hipLaunchKernelGGL(k_wf_roulette, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
+            HIP_CHECK(hipGetLastError());
+            tShade.end(stream);
+          }
           hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
           HIP_CHECK(hipGetLastError());
           std::swap(a.qA, a.qB);

@@ -31,6 +31,10 @@ __device__ __forceinline__ void traceLeanTlas(const SceneDev& sc, const SamplerC
   const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
   const float tMin = 0.001f;
   bool has = false, inMesh = false, exhausted = false, firstFill = true, pendingRetry = false, done = false;
+  // the wave's private range of the queue and the size it is topped up by: 64 .. 256 entries, at least four top-ups per wave
+  // so that the last ranges do not leave one wave walking alone
+  uint32_t chunkNext = 0, chunkEnd = 0;
+  const uint32_t chunk = leanChunk(count, nWaves);
   bool didHit = false, meshDidHit = false, rayIsWorld = false;
   uint32_t slot = 0, nodeI = 0, leftFirst = 0, span = 0, stackIdx = 0;
   float d = 0.0f;
@@ -73,20 +77,31 @@ __device__ __forceinline__ void traceLeanTlas(const SceneDev& sc, const SamplerC
     if ((nIdle >= kLeanRefill || exhausted) && done) { commit(slot, hit, didHit, attenuation, smp.dim); done = false; }
     if (nIdle == 64u && exhausted) break;
     if (!exhausted && nIdle >= kLeanRefill) {
-      uint32_t base;
+      // queue positions for the idle lanes: the first 64 by wave index; later ones from the wave's private range of the queue,
+      // which is topped up `chunk` entries at a time from the shared cursor (one atomic per chunk, not per refill: a single L2
+      // word takes ~90 atomics per microsecond, and 10 M refills per launch ran into exactly that; consecutive refills of a
+      // wave also stay in one neighbourhood of the queue — the samples of neighbouring pixels — which its L1 likes)
+      const uint32_t rank = uint32_t(__popcll(idle & laneLt));
+      uint32_t k;
       if (firstFill) {                                          // by wave index, no atomic
         firstFill = false;
-        base = waveId * 64u;
+        k = waveId * 64u + rank;
         if (nWaves * 64u >= count) exhausted = true;
       } else {
-        const int leader = __ffsll((long long) idle) - 1;
-        base = 0;
-        if (int(lane) == leader) base = atomicAdd(cursor, nIdle);
-        base = nWaves * 64u + __shfl(base, leader);
-        if (base + nIdle >= count) exhausted = true;           // wave-uniform
+        const uint32_t rem = chunkEnd - chunkNext;
+        uint32_t fresh = 0;
+        if (rem < nIdle) {                                      // (wave-uniform)
+          const int leader = __ffsll((long long) idle) - 1;
+          uint32_t c = 0;
+          if (int(lane) == leader) c = atomicAdd(cursor, chunk);
+          fresh = nWaves * 64u + __shfl(c, leader);
+        }
+        k = rank < rem ? chunkNext + rank : fresh + (rank - rem);
+        if (rem < nIdle) { chunkNext = fresh + (nIdle - rem); chunkEnd = fresh + chunk; }
+        else chunkNext += nIdle;
+        if (chunkNext >= count) exhausted = true;               // (ranges are handed out in increasing order: nothing is left behind it)
       }
       if (!has) {
-        const uint32_t k = base + uint32_t(__popcll(idle & laneLt));
         if (k < count) {
           WF_PHASE(tally, 6);                                   // refills / rays fetched
           slot = queue[k];

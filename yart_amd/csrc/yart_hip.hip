@@ -583,15 +583,11 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
 #undef YART_PICK_LEAN
   auto kExtendFast = pickExtend();
   auto kShadowFast = pickShadow();
-  // debug bit 4096: camera rays (bounce 0) through the one-ray-per-lane kernel, see the launch below (tools/b0_ab.py)
-  const bool cameraOneRay = refill && (effFlags & 4096u);
-  auto kExtendCamera = ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
   auto kRetryE = nodesForm == 3 ? k_wf_extend_retry_lean<3> : nodesForm == 2 ? k_wf_extend_retry_lean<2> : nodesForm == 1 ? k_wf_extend_retry_lean<1> : k_wf_extend_retry_lean<0>;
   auto kRetryS = nodesForm == 3 ? k_wf_shadow_retry_lean<3> : nodesForm == 2 ? k_wf_shadow_retry_lean<2> : nodesForm == 1 ? k_wf_shadow_retry_lean<1> : k_wf_shadow_retry_lean<0>;
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
   const int gridExtendFast = persistentGrid(s, reinterpret_cast<const void*>(kExtendFast), 8);
   const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);
-  const int gridExtendCamera = persistentGrid(s, reinterpret_cast<const void*>(kExtendCamera), 8);
   const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend<false>), 8);
   const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow<false>), 8);
   auto kShade = (effFlags & YART_FLAG_SHADE_SORT) ? k_wf_shade<true> : k_wf_shade<false>;
@@ -600,7 +596,6 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(kRetryS), 8);
   int gridMax = std::max(gridMega, std::max(gridExtend, gridShadow));
   gridMax = std::max(gridMax, std::max(gridExtendFast, gridShadowFast));
-  gridMax = std::max(gridMax, gridExtendCamera);
   gridMax = std::max(gridMax, std::max(gridRetryE, gridRetryS));
   s.spill.ensure(size_t(gridMax) * kBlock * kSpillDepthMax);
   // the lanes' node bitsets of the top-level-hierarchy form (trace_lean_tlas.hpp): all zero between launches
@@ -732,15 +727,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             hipLaunchKernelGGL(k_wf_extend<false>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
           } else {
             tLean.begin(stream);
-            // camera rays are coherent (a wave holds 64 samples of one pixel): their walks end together, so the
-            // one-ray-per-lane kernel — no refill rounds, no candidate masks — serves them 7 % faster (26.5 -> 24.8 ms
-            // at 1080p x 64 spp, 0.6 % of the frame). Opt-in only: one kernel per stage keeps the per-kernel launch
-            // averages of bench.py and rocprofv3 comparable. From the first bounce on the in-wave replacement wins
-            // by far (shadow rays of bounce 0: 35 vs 55 ms).
-            if (bounce == 0 && cameraOneRay)
-              hipLaunchKernelGGL(kExtendCamera, dim3(gridExtendCamera), dim3(kBlock), 0, stream, a);
-            else
-              hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
             tLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryE, dim3(gridRetryE), dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);

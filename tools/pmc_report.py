@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc results per kernel (SQ counters). Accepts output directories that
 hold either *counter_collection.csv or the rocpd sqlite database (run_results.db)."""
 import collections, csv, glob, sqlite3, sys
-names = ["k_wf_compact_commit", "k_wf_compact", "k_wf_extend_retry_lean", "k_wf_shadow_retry_lean", "k_wf_extend_lean", "k_wf_shadow_lean", "k_wf_extend_fast", "k_wf_shadow_fast", "k_wf_shadow", "k_sampler_tables", "k_wf_trace_extend", "k_wf_trace_shadow", "k_wf_extend", "k_wf_connect", "k_wf_shade", "k_wf_post", "k_wf_roulette",
+names = ["k_wf_compact_commit", "k_wf_compact", "k_wf_extend_retry_lean", "k_wf_shadow_retry_lean", "k_wf_extend_lean", "k_wf_shadow_lean", "k_wf_extend_fast", "k_wf_shadow_fast", "k_wf_shadow", "k_sampler_tables", "k_wf_trace_extend", "k_wf_trace_shadow", "k_wf_extend", "k_wf_connect", "k_wf_shade", "k_wf_roulette",
          "k_wf_generate", "k_gmon_blend", "k_render_mega"]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 info, dur = {}, collections.defaultdict(float)

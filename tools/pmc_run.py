@@ -8,7 +8,7 @@ if os.environ.get("YART_LIB") and os.environ["YART_LIB"] != "main":
     api.LIB_PATH = os.path.join(ROOT, "yart_amd", "_variants", os.environ["YART_LIB"] + ".so")
 flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 w, h, spp = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (480, 270, 32)
-scene, p = scenes.sponza_class(w, h, spp, 8, tex=256, sky=256)
+scene, p = scenes.sponza_class(w, h, spp, 8, tex=int(os.environ.get("TEX", 256)), sky=int(os.environ.get("SKY", 256)))
 ds = api.DeviceScene(scene, device=0)
 img, st = ds.render(p, flags=flags)
 print({k: st[k] for k in ("ms_device", "ms_extend", "ms_connect", "ms_shade", "traversals", "rays")})

@@ -91,15 +91,16 @@ YART_HD TexQuad texQuad(const SceneDev& sc, const TexDev& t, const TexTaps& k) {
   if (sc.texQuads != nullptr) {
     // one footprint record = the same four texels (texture.cpp:21-35 picks them; k.i00 = y * width + x names the record)
     const uint8_t* base = sc.texQuads + size_t(t.quadOffset) * 16u;
+    const uint32_t stride = t.quadStride ? t.quadStride : texQuadRecordBytes(t.channels, 0u);
     if (t.channels >= 3) {
-      const u4 v = *reinterpret_cast<const u4*>(base + size_t(k.i00) * 16u);
+      const u4 v = *reinterpret_cast<const u4*>(base + size_t(k.i00) * stride);
       q.w00 = v.x; q.w01 = v.y; q.w10 = v.z; q.w11 = v.w;
     } else if (t.channels == 2) {
-      const uint32_t* p = reinterpret_cast<const uint32_t*>(base + size_t(k.i00) * 8u);
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(base + size_t(k.i00) * stride);
       const uint32_t a = p[0], b = p[1];
       q.w00 = a & 0xffffu; q.w01 = a >> 16; q.w10 = b & 0xffffu; q.w11 = b >> 16;
     } else {
-      const uint32_t a = *reinterpret_cast<const uint32_t*>(base + size_t(k.i00) * 4u);
+      const uint32_t a = *reinterpret_cast<const uint32_t*>(base + size_t(k.i00) * stride);
       q.w00 = a & 0xffu; q.w01 = (a >> 8) & 0xffu; q.w10 = (a >> 16) & 0xffu; q.w11 = a >> 24;
     }
     return q;

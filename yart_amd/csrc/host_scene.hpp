@@ -9,6 +9,7 @@
 // bit-identical constants.
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <stdexcept>
@@ -224,6 +225,43 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
     if (m.thin_transmission && m.transmission > 0.0f) flags |= MAT_TRANSPARENT;   // :80-82
     md.flags = flags;
     im.materials.push_back(md);
+  }
+  // One 64-byte footprint record per texel position for the base-colour / normal / metal-rough maps of a material (TexDev::quadStride):
+  // materials with at least two of the three, all 8-bit and of one size, get cloned texture entries that point into an array shared by
+  // every material with the same triple. (Only the device-side footprint records are shared; the texel arrays and every value stay.)
+  {
+    std::vector<std::pair<std::array<int32_t, 3>, uint32_t>> bundles;      // (base, normal, metal-rough) -> quadOffset of the shared array
+    const uint32_t nTex = uint32_t(im.textures.size());
+    for (MaterialDev& md : im.materials) {
+      int32_t* slot[3] = {&md.texBase, &md.texNormal, &md.texMR};
+      const uint32_t at[3] = {0u, 1u, 2u};                                   // member offsets in 16-byte units: base 0, normal 16 B, metal-rough 32 B
+      uint32_t w = 0, h = 0, present = 0; bool ok = true;
+      for (int k = 0; k < 3; k++) {
+        const int32_t t = *slot[k];
+        if (t < 0) continue;
+        if (uint32_t(t) >= nTex || im.textures[t].isFloat) { ok = false; break; }
+        if (present && (im.textures[t].width != w || im.textures[t].height != h)) { ok = false; break; }
+        w = im.textures[t].width; h = im.textures[t].height; present++;
+      }
+      if (!ok || present < 2) continue;
+      const std::array<int32_t, 3> key = {*slot[0], *slot[1], *slot[2]};
+      uint32_t base = 0; bool found = false;
+      for (auto& b : bundles) if (b.first == key) { base = b.second; found = true; break; }
+      if (!found) {
+        const size_t units = size_t(w) * h * 4u;                             // 64 B per texel position
+        require(im.texQuadUnits + units < (size_t(1) << 32), "textures: more than 64 GB of footprint records");
+        base = uint32_t(im.texQuadUnits); im.texQuadUnits += units;
+        bundles.push_back({key, base});
+      }
+      for (int k = 0; k < 3; k++) {
+        if (*slot[k] < 0) continue;
+        TexDev c = im.textures[*slot[k]];
+        c.quadOffset = base + at[k]; c.quadStride = 64u;
+        // (one clone per (bundle, member) would do; a clone per material keeps this simple: TexDev is 32 bytes)
+        *slot[k] = int32_t(im.textures.size());
+        im.textures.push_back(c);
+      }
+    }
   }
 
   // ---- meshes: BVH + leaf records (mesh.hpp:27-61, bvh.hpp) --------------------

@@ -37,7 +37,11 @@ struct TexDev {            // core/texture.hpp:21-49
   // sector instead of taps in two texel rows. u8: 4 / 8 / 16 bytes per record for 1 / 2 / 3-4 channels (a tap = one word,
   // channel c in byte c); float: 4 taps x channels floats, padded to a power of two (RGB: 64 bytes). In units of 16 bytes.
   uint32_t quadOffset;
-  uint32_t pad;
+  // Bytes from one footprint record to the next; 0 = the record's own size. The base-colour, metal-rough and normal maps of a
+  // material that have the same size are laid out as ONE 64-byte record per texel position (base at byte 0, normal at 16,
+  // metal-rough at 32: host_scene.hpp clones the TexDev entries of such a material and points them into the shared array), so
+  // that the three lookups of a shaded hit — same uv, same position — touch one line and one page instead of three.
+  uint32_t quadStride;
 };
 YART_HD uint32_t texQuadRecordBytes(uint32_t channels, uint32_t isFloat) {
   if (isFloat) return channels == 1 ? 16u : channels == 2 ? 32u : 64u;

@@ -288,12 +288,13 @@ struct TexQuadArgs { const uint8_t* u8; const float* f32; TexDev t; uint8_t* out
 __global__ void __launch_bounds__(kBlock) k_tex_quads(TexQuadArgs a) {
   const uint32_t w = a.t.width, h = a.t.height, C = a.t.channels;
   const uint32_t rec = texQuadRecordBytes(C, a.t.isFloat);
+  const uint32_t stride = a.t.quadStride ? a.t.quadStride : rec;     // (a record inside a material's shared 64-byte record)
   const size_t n = size_t(w) * h;
   for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
     const uint32_t x = uint32_t(i % w), y = uint32_t(i / w);
     const uint32_t x1 = x + 1u < w ? x + 1u : x, y1 = y + 1u < h ? y + 1u : y;      // (records of the last column / row are never read)
     const size_t idx[4] = {size_t(y) * w + x, size_t(y1) * w + x, size_t(y) * w + x1, size_t(y1) * w + x1};
-    uint8_t* o = a.out + i * rec;
+    uint8_t* o = a.out + i * stride;
     if (a.t.isFloat) {
       float* of = reinterpret_cast<float*>(o);
       for (uint32_t k = 0; k < rec / 4u; k++) of[k] = 0.0f;

@@ -78,12 +78,16 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
   unsigned long long cand = 0;
 #if defined(YART_COUNT_TRAVERSAL)
   AlphaCtx actx; actx.sampler = nullptr;     // only its counters are used (YART_COUNT)
+  uint32_t boxAtFetch = 0;
 #endif
 
 #define LEAN_VISIT() (d < hit.t && (!(NEE && kFast) || !(didHit || meshDidHit) || (leftFirst & kLinkAlphaBit)))
   for (;;) {
     // ------------------------------------------------------------------ (A) retry hand-over + refill
     retry(pendingRetry, slot);
+#if defined(YART_COUNT_TRAVERSAL)
+    if (pendingRetry) tally.waste += actx.nBox - boxAtFetch;
+#endif
     pendingRetry = false;
     if (has) WF_PHASE(tally, 5);                               // outer rounds / lanes holding a ray
     const unsigned long long idle = __ballot(!has);
@@ -127,6 +131,9 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
           has = true; inMesh = false; nodeI = 0; didHit = false;
           if (!kFast) { smp = r.smp; attenuation = mk3(1.0f); }
           YART_COUNT(nTrav, 1);
+#if defined(YART_COUNT_TRAVERSAL)
+          boxAtFetch = actx.nBox;
+#endif
           cand = ~0ull;
         }
       }
@@ -187,6 +194,9 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
+                  // (the root's children are pair 0 of the top-of-tree cache)
+                  if ((MODE & TRAV_TOPCACHE) && sc.topCount != 0u && uint32_t(nd.mesh) == sc.topMesh && span == 0u)
+                    leftFirst = (leftFirst & kLinkAlphaBit) | kLinkIndexMask;
                 }
               }
             }
@@ -201,7 +211,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
 #undef LEAN_VISIT
   (void)meshHasAlpha;
 #if defined(YART_COUNT_TRAVERSAL)
-  tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
+  tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav; tally.top += actx.nTop;
 #else
   (void)tally;
 #endif

@@ -18,4 +18,3 @@ print({"box_total": c[2], "lean_extend_box": c[6], "lean_shadow_box": c[25], "re
        "wasted_over_retry_box": round((c[27] + c[31]) / max(1, retry_box), 4),
        "retry_box_per_ray": round(retry_box / max(1, c[29] + c[30]), 1),
        "wasted_box_per_ray": round((c[27] + c[31]) / max(1, c[29] + c[30]), 1)}, flush=True)
-print({"lean_extend_box_from_lds": c[8], "share": round(c[8] / max(1, c[6]), 4), "lean_shadow_box_from_lds": c[9], "share_shadow": round(c[9] / max(1, c[25]), 4)}, flush=True)

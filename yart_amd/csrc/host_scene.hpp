@@ -56,8 +56,6 @@ struct HostImage {
   std::vector<float> areaPowerCdf;
   std::vector<float> lut;                          // LutDev layout (incl. Sobol matrix bits)
   std::vector<std::vector<uint32_t>> bvhIndices;   // per mesh, for yart_hip_bvh_copy
-  std::vector<BvhNode> topPairs;                   // top-of-tree cache of the lean kernels (SceneDev::topPairs)
-  uint32_t topMesh = 0, topCount = 0;
   float totalPower = 0.0f;
   uint32_t maxNodeDepth = 0;
   uint32_t nLights = 0, nInfinite = 0, nArea = 0, nMaterials = 0;   // real counts (the vectors are padded)
@@ -71,7 +69,6 @@ struct HostImage {
     SceneDev s{};
     s.shadeTris = shadeTris.data();
     s.bvhNodes = bvhNodes.data(); s.leafTris = leafTris.data(); s.triVerts = triVerts.data();
-    s.topPairs = topPairs.data(); s.topMesh = topMesh; s.topCount = topCount;
     s.triLight = triLight.data(); s.vPos = vPos.data(); s.vNormal = vNormal.data();
     s.vTangent = vTangent.data(); s.vUV = vUV.data(); s.meshes = meshes.data(); s.nodes = nodes.data();
     s.materials = materials.data(); s.textures = textures.data(); s.texU8 = texU8.data();
@@ -158,54 +155,6 @@ inline void appendLutFootprints(std::vector<float>& lut) {
         o[2] = at(LutDev::baseEavg, (i + 1) * 16 + j); o[3] = at(LutDev::baseEavg, (i + 1) * 16 + j1);
       }
   }
-}
-
-// Top-of-tree cache of the lean traversal kernels (scene_types.hpp::kTopLinkMin): of the scene's largest mesh, the sibling pairs
-// whose parents have the largest surface area — for rays without a preferred position the probability of a visit is proportional
-// to it — taken greedily from the root down (a parent is always cached before its children, so every cached pair is reached
-// through cached links only). The records are copies of the tree's own (same boxes, same spans, same alpha bits); only the links
-// to pairs that are in the table themselves are rewritten. Nothing about the walk changes: it is the same tree.
-inline void buildTopCache(HostImage& im, uint32_t maxPairs = kTopSlots) {
-  im.topPairs.clear(); im.topCount = 0; im.topMesh = 0;
-  if (const char* e = std::getenv("YART_TOP_PAIRS")) maxPairs = std::min<uint32_t>(maxPairs, uint32_t(std::atoi(e)));
-  uint32_t best = ~0u;
-  for (uint32_t m = 0; m < im.meshes.size(); m++) {
-    if (im.meshes[m].nNodes >= kTopLinkMin || im.meshes[m].nTris >= kTopLinkMin) return;      // (index space taken: no cache)
-    if (best == ~0u || im.meshes[m].nNodes > im.meshes[best].nNodes) best = m;
-  }
-  if (best == ~0u || maxPairs == 0) return;
-  const BvhNode* nodes = im.bvhNodes.data() + im.meshes[best].nodeOffset;
-  if (nodes[0].span != 0) return;                                                             // a single leaf
-  auto area = [&](uint32_t n) {
-    const float ex = nodes[n].bmax[0] - nodes[n].bmin[0], ey = nodes[n].bmax[1] - nodes[n].bmin[1], ez = nodes[n].bmax[2] - nodes[n].bmin[2];
-    const float a = ex * ey + ey * ez + ez * ex;
-    return a == a ? a : 0.0f;
-  };
-  std::vector<std::pair<float, uint32_t>> heap;          // (area, inner node)
-  auto less = [](const std::pair<float, uint32_t>& x, const std::pair<float, uint32_t>& y) {
-    return x.first < y.first || (x.first == y.first && x.second > y.second);
-  };
-  heap.push_back({area(0), 0u});
-  std::vector<uint32_t> slotNode;
-  std::vector<uint32_t> slotOf(im.meshes[best].nNodes, ~0u);
-  while (!heap.empty() && slotNode.size() < maxPairs) {
-    std::pop_heap(heap.begin(), heap.end(), less);
-    const uint32_t n = heap.back().second; heap.pop_back();
-    slotOf[n] = uint32_t(slotNode.size()); slotNode.push_back(n);
-    const uint32_t l = nodes[n].leftFirst & kLinkIndexMask;
-    for (uint32_t c = l; c < l + 2u; c++)
-      if (nodes[c].span == 0) { heap.push_back({area(c), c}); std::push_heap(heap.begin(), heap.end(), less); }
-  }
-  im.topPairs.resize(slotNode.size() * 2);
-  for (size_t s = 0; s < slotNode.size(); s++) {
-    const uint32_t l = nodes[slotNode[s]].leftFirst & kLinkIndexMask;
-    for (uint32_t k = 0; k < 2u; k++) {
-      BvhNode r = nodes[l + k];
-      if (r.span == 0 && slotOf[l + k] != ~0u) r.leftFirst = (r.leftFirst & kLinkAlphaBit) | (kLinkIndexMask - slotOf[l + k]);
-      im.topPairs[2 * s + k] = r;
-    }
-  }
-  im.topMesh = best; im.topCount = uint32_t(slotNode.size());
 }
 
 inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullptr, void* bvhCtx = nullptr) {

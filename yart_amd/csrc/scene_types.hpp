@@ -68,11 +68,6 @@ constexpr uint32_t kLinkAlphaBit = 1u << 26;
 // traversal-stack link word: index | alpha bit | leaf span << 27 (5 bits, 31 = "31 or more": traverse.hpp::leafSpan
 // then reads the true span from bits 8..31 of the matFlags word of the leaf's first LeafTri)
 constexpr uint32_t kSpanShift = 27, kSpanBig = 31, kLeafSpanShift = 8;
-// Top-of-tree cache of the lean traversal kernels (SceneDev::topPairs, trace_lean_bvh2.inc): the sibling pairs a ray is most
-// likely to visit, copied into LDS by every workgroup. A link to a cached pair is kLinkIndexMask - slot: the top kTopSlots
-// values of the 26-bit index space, which no real node or leaf index reaches (meshes of the cached scene are checked).
-constexpr uint32_t kTopSlots = 4096;
-constexpr uint32_t kTopLinkMin = kLinkIndexMask - (kTopSlots - 1u);
 
 struct BvhNode {           // core/bvh.hpp:21-33 (32 bytes)
   float bmin[3];
@@ -205,13 +200,9 @@ struct SceneDev {
   const uint32_t* areaLights;       // indices into lights
   const float* areaPowerCdf;        // m_lightPowers, light-sampler.cpp:43-47
   const float* lut;                 // LutDev layout
-  // top-of-tree cache (kTopLinkMin): topCount sibling pairs (2 records each) of mesh topMesh, child links rewritten to cached
-  // links where the child's own pair is in the table; pair 0 is the root's children. topCount = 0: no cache.
-  const BvhNode* topPairs;
   uint32_t nNodes, nLights, nInfinite, nArea;
   float totalPower;
-  uint32_t topMesh, topCount;
-  uint32_t pad[1];
+  uint32_t pad[3];
 };
 
 struct Hit {                   // cpu/hit.hpp:8-17 after testNode returned

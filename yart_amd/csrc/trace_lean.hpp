@@ -194,9 +194,6 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
-                  // (the root's children are pair 0 of the top-of-tree cache)
-                  if ((MODE & TRAV_TOPCACHE) && sc.topCount != 0u && uint32_t(nd.mesh) == sc.topMesh && span == 0u)
-                    leftFirst = (leftFirst & kLinkAlphaBit) | kLinkIndexMask;
                 }
               }
             }
@@ -211,7 +208,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
 #undef LEAN_VISIT
   (void)meshHasAlpha;
 #if defined(YART_COUNT_TRAVERSAL)
-  tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav; tally.top += actx.nTop;
+  tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
 #else
   (void)tally;
 #endif

@@ -43,13 +43,8 @@ YART_HD bool testBox(const RayO& r, float tIntMin, float tIntMax, const float* b
   float lo_x = r.sx ? bmax[0] : bmin[0], hi_x = r.sx ? bmin[0] : bmax[0];
   float lo_y = r.sy ? bmax[1] : bmin[1], hi_y = r.sy ? bmin[1] : bmax[1];
   float lo_z = r.sz ? bmax[2] : bmin[2], hi_z = r.sz ? bmin[2] : bmax[2];
-#if defined(YART_EXP_BOX_FMA)
-  float tmin0 = __builtin_fmaf(lo_x, r.idir.x, r.odir.x), tmin1 = __builtin_fmaf(lo_y, r.idir.y, r.odir.y), tmin2 = __builtin_fmaf(lo_z, r.idir.z, r.odir.z);
-  float tmax0 = __builtin_fmaf(hi_x, r.idir.x, r.odir.x), tmax1 = __builtin_fmaf(hi_y, r.idir.y, r.odir.y), tmax2 = __builtin_fmaf(hi_z, r.idir.z, r.odir.z);
-#else
   float tmin0 = lo_x * r.idir.x + r.odir.x, tmin1 = lo_y * r.idir.y + r.odir.y, tmin2 = lo_z * r.idir.z + r.odir.z;
   float tmax0 = hi_x * r.idir.x + r.odir.x, tmax1 = hi_y * r.idir.y + r.odir.y, tmax2 = hi_z * r.idir.z + r.odir.z;
-#endif
   // Reference: t0 = max(tmin[i], t0) with max(m,n) = m > n ? m : n, t1 = min(tmax[i], t1)
   // likewise. t0 / t1 themselves are never NaN (they start from tMin / hit.t and a NaN
   // candidate loses the comparison), so IEEE maxNum / minNum — which also return the
@@ -74,20 +69,14 @@ YART_HD void testBox2(const RayO& r, float tIntMin, float tIntMax, const BvhNode
 // The LDS part is addressed through an LDS-address-space pointer so that it compiles to
 // ds_write_b64 / ds_read_b64 (a generic pointer selected against the spill pointer turns
 // every pop into a flat_load with a full vmcnt+lgkmcnt wait).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// (by value: __builtin_bit_cast applied directly to an element of an ext_vector reads element 0 with this compiler)
-YART_HD float bitsToFloat(uint32_t u) { return __builtin_bit_cast(float, u); }
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
-typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 #else
 typedef uint64_t lds_u64;
-typedef u32x4 lds_u32x4;
 #endif
 struct TravStack {
   lds_u64* lds; uint32_t ldsStride; uint32_t ldsDepth;
   uint64_t* spill; uint32_t spillStride;
-  const lds_u32x4* top = nullptr;      // TRAV_TOPCACHE: the workgroup's LDS copy of SceneDev::topPairs (4 x 16 B per pair)
 };
 YART_HD void stackPush(const TravStack& s, uint32_t k, uint32_t node, float d) {
   uint32_t db = __builtin_bit_cast(uint32_t, d);
@@ -128,14 +117,14 @@ struct HitRec {              // what the walk tracks of cpu/hit.hpp
 //   TRAV_IDENTITY  every scene node's transform chain is the identity (checked at scene build):
 //                  no 4x4 products, the world ray (+0) is used for every node; ~30 VGPRs.
 // Together they bring the closest-hit kernel from 127 to 74 VGPRs, i.e. from 4 to 6 waves/SIMD.
-enum : int { TRAV_GENERAL = 0, TRAV_FAST = 1, TRAV_IDENTITY = 2, TRAV_TOPCACHE = 4 };
+enum : int { TRAV_GENERAL = 0, TRAV_FAST = 1, TRAV_IDENTITY = 2 };
 
 struct AlphaCtx {            // state the stochastic alpha test draws from
   Sampler* sampler;
   SamplerConfig cfg;
   bool deferred = false;     // TRAV_FAST: the ray met an alpha / transparent candidate
 #if defined(YART_COUNT_TRAVERSAL)
-  uint32_t nBox = 0, nTri = 0, nTrav = 0, nTop = 0;
+  uint32_t nBox = 0, nTri = 0, nTrav = 0;
 #endif
 };
 

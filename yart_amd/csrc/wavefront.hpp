@@ -30,7 +30,6 @@ struct WfState {
 struct WfTally {
 #if defined(YART_COUNT_TRAVERSAL)
   uint32_t box = 0, tri = 0, trav = 0, shade = 0;
-  uint32_t top = 0;            // box tests whose sibling pair came from the LDS copy of the top of the tree
   uint32_t waste = 0;          // box tests the lean kernels spent on rays they then handed to the general kernels
 #endif
 #if defined(YART_TRACE_STATS)

@@ -334,7 +334,7 @@ struct YartScene {
   SceneDev dev{};
   int numCUs = 256;
   // device copies of the scene image
-  DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<BvhNode> topPairs; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
+  DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32; DevBuf<uint8_t> texQuads;
   DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld; DevBuf<TlasNode> tlas; DevBuf<unsigned long long> nodeBits;
@@ -364,7 +364,7 @@ namespace {
 void uploadScene(YartScene& s) {
   const HostImage& h = s.host;
   s.shadeTris.upload(h.shadeTris);
-  s.bvhNodes.upload(h.bvhNodes); s.leafTris.upload(h.leafTris); s.triVerts.upload(h.triVerts); s.topPairs.upload(h.topPairs);
+  s.bvhNodes.upload(h.bvhNodes); s.leafTris.upload(h.leafTris); s.triVerts.upload(h.triVerts);
   s.triLight.upload(h.triLight); s.vPos.upload(h.vPos); s.vNormal.upload(h.vNormal);
   s.vTangent.upload(h.vTangent); s.vUV.upload(h.vUV); s.meshes.upload(h.meshes); s.nodes.upload(h.nodes);
   s.materials.upload(h.materials); s.textures.upload(h.textures); s.texU8.upload(h.texU8);
@@ -388,7 +388,7 @@ void uploadScene(YartScene& s) {
   HIP_CHECK(hipDeviceSynchronize());
   SceneDev d = h.view();       // counts and totals; pointers replaced below
   d.shadeTris = s.shadeTris.p;
-  d.bvhNodes = s.bvhNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p; d.topPairs = s.topPairs.p;
+  d.bvhNodes = s.bvhNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
   d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.texQuads = s.texQuads.p; d.lights = s.lights.p; d.envs = s.envs.p;
@@ -431,7 +431,6 @@ YartScene* createScene(const YartSceneDesc& desc, int device, uint32_t sceneFlag
   // for the host builder; the two give the same bytes, and every GPU test that compares a frame with the reference's checks it
   if ((sceneFlags & YART_SCENE_HOST_BVH) || std::getenv("YART_HOST_BVH")) s->host = buildHostImage(desc);
   else s->host = buildHostImage(desc, deviceMeshBvh, &dev);
-  buildTopCache(s->host, kLeanTopPairs);        // as many pairs as the lean kernels keep in LDS
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, dev));
   s->numCUs = prop.multiProcessorCount;

@@ -150,6 +150,8 @@ typedef struct YartRenderParams {
 #define YART_FLAG_NO_SHADE_SORT 64u /* shade the queue entries in queue order */
 #define YART_FLAG_DIRECT_SAMPLER 8u /* evaluate every ZSobol index digit per draw (no per-render sampler tables) */
 #define YART_FLAG_NO_COMPACTION 32u  /* keep every bounce on the batch-sized path state (no copy of the survivors into a dense one) */
+#define YART_FLAG_NO_RESUME 128u    /* rays the lean traversal kernels hand to the general ones are traced again from the root instead of
+                                       being taken up where the lean kernel stood (the default; same frame either way) */
 #define YART_FLAG_GENERAL_TRACE 4u  /* general traversal kernels for every ray instead of lean kernels + retry */
 
 /* Renderer::RenderData counters (src/core/renderer.hpp:22-28) + per-stage device time. */

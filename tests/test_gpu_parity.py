@@ -36,6 +36,8 @@ def api(built):
 PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+shade_sort": 2, "wavefront+general_trace": 4,
                   "wavefront+direct_sampler": 8, "wavefront+no_refill": 16, "wavefront+no_compaction": 32,
                   "wavefront+no_shade_sort": 64,
+                  # rays the lean kernels hand over are traced again from the root instead of being resumed
+                  "wavefront+no_resume": 128,
                   # scenes of 64 nodes and more take their candidate windows from the top-level hierarchy by default; the two
                   # forms without it: chunked candidate masks / per-lane walk of the node list by size (262144), the walk (65536)
                   "wavefront+node_masks": 262144, "wavefront+node_walk": 65536}
@@ -185,10 +187,40 @@ def test_sponza_class_pipelines_agree(api):
     scene = api.DeviceScene(s, device=0)
     a, st = scene.render(p)
     assert st["rays"] > 0 and np.isfinite(a).all()
-    for name in ("megakernel", "wavefront+no_shade_sort", "wavefront+general_trace", "wavefront+no_refill", "wavefront"):
+    for name in ("megakernel", "wavefront+no_shade_sort", "wavefront+general_trace", "wavefront+no_refill", "wavefront+no_resume", "wavefront"):
         b, st2 = scene.render(p, flags=PIPELINE_FLAGS[name])
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
         assert st2["rays"] == st["rays"], name
+    scene.close()
+
+
+def test_resumed_walks_equal_restarted_walks(api, monkeypatch):
+    """Rays the lean kernels hand to the general ones are taken up where the lean kernel stood (resume records: scene node,
+    hit so far, leaf, traversal stack) — except shadow rays that are occluded already, rays with deep stacks and rays that find
+    no record left, which are traced again from the root. Same frame whichever way a ray goes: all records, a few, none
+    (YART_RESUME_CAP), and the flag that switches the records off; the counting build says how many rays went which way."""
+    from yart_amd import scenes
+    s, p = scenes.sponza_class(200, 112, 8, 8, tex=256, sky=256)
+    scene = api.DeviceScene(s, device=0, instrumented=True)
+    ref, st0 = scene.render(p, flags=PIPELINE_FLAGS["wavefront+no_resume"])
+    c = scene.debug_counters()
+    handed = int(c[29]) + int(c[30])
+    assert handed > 1000 and int(c[8]) == 0 and int(c[9]) == 0
+    seen = {}
+    for cap in (None, "64", "0"):
+        if cap is None:
+            monkeypatch.delenv("YART_RESUME_CAP", raising=False)
+        else:
+            monkeypatch.setenv("YART_RESUME_CAP", cap)
+        img, st = scene.render(p)
+        c = scene.debug_counters()
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"YART_RESUME_CAP={cap}"
+        assert st["rays"] == st0["rays"] and int(c[29]) + int(c[30]) == handed
+        seen[cap] = (int(c[8]), int(c[9]))
+    monkeypatch.delenv("YART_RESUME_CAP", raising=False)
+    assert seen[None][0] > 0.9 * int(c[29]) and seen[None][1] > 0          # closest-hit rays: (nearly) all resumed
+    assert 0 < sum(seen["64"]) < sum(seen[None])                             # a few records per launch, the rest restarted
+    assert seen["0"] == (0, 0)
     scene.close()
 
 

@@ -38,6 +38,7 @@ FLAG_DIRECT_SAMPLER = 8
 FLAG_NO_REFILL = 16
 FLAG_NO_COMPACTION = 32
 FLAG_NO_SHADE_SORT = 64
+FLAG_NO_RESUME = 128
 
 
 class YartError(RuntimeError):

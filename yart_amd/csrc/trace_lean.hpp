@@ -65,6 +65,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
   // so that the last ranges do not leave one wave walking alone
   uint32_t chunkNext = 0, chunkEnd = 0;
   const uint32_t chunk = leanChunk(count, nWaves);
+  uint32_t recNext = 0, recEnd = 0;                            // the wave's private range of resume records (64 per atomic)
   bool didHit = false, meshDidHit = false, rayIsWorld = false;
   uint32_t slot = 0, nodeI = 0, leftFirst = 0, span = 0, stackIdx = 0;
   float d = 0.0f;
@@ -84,7 +85,45 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
 #define LEAN_VISIT() (d < hit.t && (!(NEE && kFast) || !(didHit || meshDidHit) || (leftFirst & kLinkAlphaBit)))
   for (;;) {
     // ------------------------------------------------------------------ (A) retry hand-over + refill
-    retry(pendingRetry, slot);
+    if (kFast) {
+      // A ray that met an alpha / transparent candidate goes to the general kernel WITH ITS WALK: scene node, candidate mask, hit so
+      // far, the leaf it stands at and the traversal stack (traverse.hpp: resume record). The general kernel takes the walk up at
+      // that leaf — testing a leaf again from its first triangle changes nothing: what was accepted is now rejected by hit.t <= t,
+      // what was rejected is rejected again — instead of repeating it from the root (76 % of the general kernels' box tests were
+      // such repeats, profiles/r3_ab_top_cache.txt). Not for a shadow ray that is occluded already: from then on the lean walk
+      // skips subtrees without alpha-tested triangles, which the general walk — the reference's — does not.
+      uint32_t word = slot;
+      if (stk.rec != nullptr && __ballot(pendingRetry) != 0ull) {
+        const bool can = pendingRetry && stackIdx <= kResumeStack && !(NEE && (didHit || meshDidHit));
+        const unsigned long long mc = __ballot(can);
+        const uint32_t need = uint32_t(__popcll(mc));
+        if (need != 0u) {
+          if (recEnd - recNext < need) {                          // (wave-uniform; what is left of the old range is not used)
+            const int leader = __ffsll((long long) mc) - 1;
+            uint32_t c = 0;
+            if (int(lane) == leader) c = atomicAdd(stk.recCursor, 64u);
+            recNext = __shfl(c, leader); recEnd = recNext + 64u;
+          }
+          const uint32_t idx = recNext + uint32_t(__popcll(mc & laneLt));
+          recNext += need;
+          if (can && idx < stk.recCap) {
+            f4* r = stk.rec + size_t(idx) * kResumeWords;
+            wfSt(r + 0, mk4(asF(slot), asF(nodeI), asF((didHit ? 1u : 0u) | (meshDidHit ? 2u : 0u) | (stackIdx << 8)), asF(packLink(leftFirst, span))));
+            wfSt(r + 1, mk4(d, hit.t, hit.u, hit.v));
+            wfSt(r + 2, mk4(asF(hit.tri), asF(hit.node), asF(hit.backSide), asF(uint32_t(cand))));
+            wfSt(r + 3, mk4(asF(uint32_t(cand >> 32)), 0.0f, 0.0f, 0.0f));
+            for (uint32_t k = 0; k < stackIdx; k += 2u) {
+              const uint64_t e0 = stackPeek(stk, k), e1 = k + 1u < stackIdx ? stackPeek(stk, k + 1u) : 0ull;
+              wfSt(r + 4 + (k >> 1), mk4(asF(uint32_t(e0)), asF(uint32_t(e0 >> 32)), asF(uint32_t(e1)), asF(uint32_t(e1 >> 32))));
+            }
+            word = idx | kResumeFlag;
+          }
+        }
+      }
+      retry(pendingRetry, word);
+    } else {
+      retry(pendingRetry, slot);
+    }
 #if defined(YART_COUNT_TRAVERSAL)
     if (pendingRetry) tally.waste += actx.nBox - boxAtFetch;
 #endif
@@ -124,7 +163,12 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
       if (!has) {
         if (k < count) {
           WF_PHASE(tally, 6);                                   // refills / rays fetched
-          slot = queue[k];
+          const uint32_t word = queue[k];
+          const bool resumed = !kFast && (word & kResumeFlag) != 0u;
+          const f4* rec = stk.rec + size_t(word & ~kResumeFlag) * kResumeWords;
+          f4 w0 = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (resumed) w0 = wfLd(rec);
+          slot = resumed ? asU(w0.x) : word;
           const LeanRay r = fetch(slot);
           ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true;
           hit.t = r.tMax; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
@@ -135,6 +179,35 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
           boxAtFetch = actx.nBox;
 #endif
           cand = ~0ull;
+          if (resumed) {
+            // the walk as the lean kernel left it: inside the mesh of scene node nodeI, at a leaf, with its stack (at most
+            // kResumeStack entries: they fit the LDS part of this kernel's stack)
+            const f4 w1 = wfLd(rec + 1), w2 = wfLd(rec + 2), w3 = wfLd(rec + 3);
+            nodeI = asU(w0.y);
+            const uint32_t fl = asU(w0.z), link = asU(w0.w);
+            didHit = (fl & 1u) != 0u; meshDidHit = (fl & 2u) != 0u; stackIdx = fl >> 8;
+            leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
+            d = w1.x; hit.t = w1.y; hit.u = w1.z; hit.v = w1.w;
+            hit.tri = asU(w2.x); hit.node = asU(w2.y); hit.backSide = asU(w2.z);
+            cand = uint64_t(asU(w2.w)) | (uint64_t(asU(w3.x)) << 32);
+            for (uint32_t j = 0; j < stackIdx; j += 2u) {
+              const f4 e = wfLd(rec + 4 + (j >> 1));
+              stackPoke(stk, j, uint64_t(asU(e.x)) | (uint64_t(asU(e.y)) << 32));
+              if (j + 1u < stackIdx) stackPoke(stk, j + 1u, uint64_t(asU(e.z)) | (uint64_t(asU(e.w)) << 32));
+            }
+            const NodeDev& nd = sc.nodes[nodeI];
+            if (!((MODE & TRAV_IDENTITY) || (nd.pad[0] & 1u))) {
+              f3 oo, od;
+              objectRay(sc, nodeI, r.o, r.d, oo, od);
+              ray = makeRay(oo, od); rayIsWorld = false;
+            }
+            const MeshDev& mesh = sc.meshes[nd.mesh];
+            nodes = sc.bvhNodes + mesh.nodeOffset;
+            leaves = sc.leafTris + mesh.leafOffset;
+            meshHasAlpha = mesh.hasAlpha != 0;
+            inMesh = true;
+            YART_COUNT(nResumed, 1);
+          }
         }
       }
       // candidate masks of the new rays: one pass over the node boxes (wave-uniform addresses)
@@ -208,7 +281,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
 #undef LEAN_VISIT
   (void)meshHasAlpha;
 #if defined(YART_COUNT_TRAVERSAL)
-  tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav;
+  tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav; tally.resumed += actx.nResumed;
 #else
   (void)tally;
 #endif

@@ -74,9 +74,18 @@ typedef __attribute__((address_space(3))) uint64_t lds_u64;
 #else
 typedef uint64_t lds_u64;
 #endif
+// Walks the lean kernels hand to the general ones are RESUMED, not restarted (trace_lean.hpp): one record per handed-over ray.
+//   word 0: path slot, scene node, flags (bit 0 didHit, bit 1 meshDidHit, bits 8.. stack entries), link word of the leaf
+//   word 1: the leaf's entry distance, hit.t, hit.u, hit.v      word 2: hit.tri, hit.node, hit.backSide, candidate mask (low)
+//   word 3: candidate mask (high), -, -, -                        words 4..11: the traversal stack, two entries per word
+constexpr uint32_t kResumeStack = 16;                              // deeper stacks: the ray is restarted instead
+constexpr uint32_t kResumeWords = 4 + kResumeStack / 2;            // 16-byte words per record (192 B)
+constexpr uint32_t kResumeFlag = 0x80000000u;                      // retry-queue word = record index | flag (plain word = slot: restart)
 struct TravStack {
   lds_u64* lds; uint32_t ldsStride; uint32_t ldsDepth;
   uint64_t* spill; uint32_t spillStride;
+  // resume records of this launch (null: every hand-over is a restart): written by the lean kernels, read by the general ones
+  f4* rec = nullptr; uint32_t* recCursor = nullptr; uint32_t recCap = 0;
 };
 YART_HD void stackPush(const TravStack& s, uint32_t k, uint32_t node, float d) {
   uint32_t db = __builtin_bit_cast(uint32_t, d);
@@ -90,6 +99,14 @@ YART_HD void stackPop(const TravStack& s, uint32_t k, uint32_t& node, float& d) 
   else e = s.spill[(k - s.ldsDepth) * s.spillStride];
   node = uint32_t(e);
   d = __builtin_bit_cast(float, uint32_t(e >> 32));
+}
+
+YART_HD uint64_t stackPeek(const TravStack& s, uint32_t k) {
+  return k < s.ldsDepth ? s.lds[k * s.ldsStride] : s.spill[(k - s.ldsDepth) * s.spillStride];
+}
+YART_HD void stackPoke(const TravStack& s, uint32_t k, uint64_t e) {
+  if (k < s.ldsDepth) s.lds[k * s.ldsStride] = e;
+  else s.spill[(k - s.ldsDepth) * s.spillStride] = e;
 }
 
 struct HitRec {              // what the walk tracks of cpu/hit.hpp
@@ -124,7 +141,7 @@ struct AlphaCtx {            // state the stochastic alpha test draws from
   SamplerConfig cfg;
   bool deferred = false;     // TRAV_FAST: the ray met an alpha / transparent candidate
 #if defined(YART_COUNT_TRAVERSAL)
-  uint32_t nBox = 0, nTri = 0, nTrav = 0;
+  uint32_t nBox = 0, nTri = 0, nTrav = 0, nResumed = 0;
 #endif
 };
 

@@ -30,6 +30,7 @@ struct WfState {
 struct WfTally {
 #if defined(YART_COUNT_TRAVERSAL)
   uint32_t box = 0, tri = 0, trav = 0, shade = 0;
+  uint32_t resumed = 0;        // handed-over rays the general kernels took up where the lean kernel stood
   uint32_t waste = 0;          // box tests the lean kernels spent on rays they then handed to the general kernels
 #endif
 #if defined(YART_TRACE_STATS)

@@ -334,7 +334,7 @@ struct YartScene {
   SceneDev dev{};
   int numCUs = 256;
   // device copies of the scene image
-  DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
+  DevBuf<f4> resumeRec; DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32; DevBuf<uint8_t> texQuads;
   DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld; DevBuf<TlasNode> tlas; DevBuf<unsigned long long> nodeBits;
@@ -615,7 +615,8 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const uint32_t waveCap = std::max(std::min(p.first_wave_samples, p.samples), maxWave);
   size_t freeB = 0, totalB = 0;
   HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
-  uint64_t held = uint64_t(s.L.n) * 16 + (uint64_t(s.qA.n) + s.qB.n + s.qS.n + s.qR.n) * 4;
+  uint64_t held = uint64_t(s.L.n) * 16 + (uint64_t(s.qA.n) + s.qB.n + s.qS.n + s.qR.n) * 4 + uint64_t(s.resumeRec.n) * 16;
+  uint32_t resumeCap = 0;
   for (auto& b : s.wf) held += uint64_t(b.n) * 16;
   for (auto& t : s.wfTail) for (auto& b : t) held += uint64_t(b.n) * 16;
   held += (uint64_t(s.wfTailMap[0].n) + s.wfTailMap[1].n) * 4;
@@ -641,6 +642,17 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       s.wfDyn.ensure(1);
     }
     s.qA.ensure(np); s.qB.ensure(np); s.qS.ensure(np); s.qR.ensure(np); s.wfCounters.ensure(WC_COUNT);
+    // resume records of the rays the lean kernels hand to the general ones (traverse.hpp: 192 B each): room for an eighth of
+    // the batch (C3 hands over 6-7 % of its rays; a ray that finds no record is restarted, as all of them were before). Taken
+    // from the share of the memory the batch leaves free. YART_RESUME_CAP: records (tests of the fallback), 0 = restarts only.
+    if (!(p.flags & YART_FLAG_NO_RESUME)) {
+      // (+ one range of 64 per wave of the largest grid: a wave takes its records 64 at a time and may leave a range unfinished)
+      size_t cap = std::max<size_t>(np / 8, std::min<size_t>(np, 1u << 16)) + size_t(gridMax) * kBlock;
+      if (const char* e = std::getenv("YART_RESUME_CAP")) cap = size_t(std::atoll(e));
+      cap = std::min<size_t>(cap, 0x7fffff00u);
+      if (cap) s.resumeRec.ensure(cap * kResumeWords);
+      resumeCap = uint32_t(cap);
+    }
   }
 
   Timer tAll;
@@ -702,6 +714,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         a.pixels = s.pixels.p + c0; a.nPaths = n * uint32_t(waveSamples); a.spp = uint32_t(waveSamples);
         a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p; a.stats = s.counters.p; a.spill = s.spill.p;
         a.matClass = s.matClass.p;
+        a.resumeRec = resumeCap ? s.resumeRec.p : nullptr; a.resumeCap = resumeCap;
         a.sc.nodeBits = s.nodeBits.p; a.sc.nodeBitWords = nodeBitWords;
         if (compact) {
           for (int t = 0; t < 2; t++) {
@@ -715,7 +728,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           HIP_CHECK(hipMemcpyAsync(s.wfDyn.p, &d0, sizeof(d0), hipMemcpyHostToDevice, stream));
           a.dyn = s.wfDyn.p;
         }
-        const uint32_t init[WC_COUNT] = {a.nPaths, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t init[WC_COUNT] = {a.nPaths, 0, 0, 0, 0, 0, 0, 0, 0};
         HIP_CHECK(hipMemcpyAsync(s.wfCounters.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
         tShade.begin(stream);
         hipLaunchKernelGGL(k_wf_generate, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);

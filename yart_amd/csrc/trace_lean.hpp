@@ -109,12 +109,12 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
           if (can && idx < stk.recCap) {
             f4* r = stk.rec + size_t(idx) * kResumeWords;
             wfSt(r + 0, mk4(asF(slot), asF(nodeI), asF((didHit ? 1u : 0u) | (meshDidHit ? 2u : 0u) | (stackIdx << 8)), asF(packLink(leftFirst, span))));
-            wfSt(r + 1, mk4(d, hit.t, hit.u, hit.v));
-            wfSt(r + 2, mk4(asF(hit.tri), asF(hit.node), asF(hit.backSide), asF(uint32_t(cand))));
-            wfSt(r + 3, mk4(asF(uint32_t(cand >> 32)), 0.0f, 0.0f, 0.0f));
+            wfSt(r + 1, mk4(d, hit.t, asF(uint32_t(cand)), asF(uint32_t(cand >> 32))));
+            // (a shadow ray that has a hit is not resumed; a closest-hit ray without one has nothing to say here)
+            if (!NEE && (didHit || meshDidHit)) wfSt(r + 2, mk4(hit.u, hit.v, asF(hit.tri), asF(hit.node | (hit.backSide << kWfNodeBits))));
             for (uint32_t k = 0; k < stackIdx; k += 2u) {
               const uint64_t e0 = stackPeek(stk, k), e1 = k + 1u < stackIdx ? stackPeek(stk, k + 1u) : 0ull;
-              wfSt(r + 4 + (k >> 1), mk4(asF(uint32_t(e0)), asF(uint32_t(e0 >> 32)), asF(uint32_t(e1)), asF(uint32_t(e1 >> 32))));
+              wfSt(r + 3 + (k >> 1), mk4(asF(uint32_t(e0)), asF(uint32_t(e0 >> 32)), asF(uint32_t(e1)), asF(uint32_t(e1 >> 32))));
             }
             word = idx | kResumeFlag;
           }
@@ -164,11 +164,13 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
         if (k < count) {
           WF_PHASE(tally, 6);                                   // refills / rays fetched
           const uint32_t word = queue[k];
-          const bool resumed = !kFast && (word & kResumeFlag) != 0u;
+          const bool hasRec = !kFast && (word & kResumeFlag) != 0u && (word & ~kResumeFlag) < stk.recCap;
           const f4* rec = stk.rec + size_t(word & ~kResumeFlag) * kResumeWords;
           f4 w0 = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (resumed) w0 = wfLd(rec);
-          slot = resumed ? asU(w0.x) : word;
+          if (hasRec) w0 = wfLd(rec);
+          slot = hasRec ? asU(w0.x) : word;
+          // (a record that does not name a mesh node of this scene is not followed: the ray is traced from the root)
+          const bool resumed = hasRec && asU(w0.y) < sc.nNodes && sc.nodes[asU(w0.y) < sc.nNodes ? asU(w0.y) : 0u].mesh >= 0;
           const LeanRay r = fetch(slot);
           ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true;
           hit.t = r.tMax; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
@@ -182,16 +184,20 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
           if (resumed) {
             // the walk as the lean kernel left it: inside the mesh of scene node nodeI, at a leaf, with its stack (at most
             // kResumeStack entries: they fit the LDS part of this kernel's stack)
-            const f4 w1 = wfLd(rec + 1), w2 = wfLd(rec + 2), w3 = wfLd(rec + 3);
+            const f4 w1 = wfLd(rec + 1);
             nodeI = asU(w0.y);
             const uint32_t fl = asU(w0.z), link = asU(w0.w);
             didHit = (fl & 1u) != 0u; meshDidHit = (fl & 2u) != 0u; stackIdx = fl >> 8;
             leftFirst = link & ((1u << kSpanShift) - 1u); span = link >> kSpanShift;
-            d = w1.x; hit.t = w1.y; hit.u = w1.z; hit.v = w1.w;
-            hit.tri = asU(w2.x); hit.node = asU(w2.y); hit.backSide = asU(w2.z);
-            cand = uint64_t(asU(w2.w)) | (uint64_t(asU(w3.x)) << 32);
+            d = w1.x; hit.t = w1.y;
+            cand = uint64_t(asU(w1.z)) | (uint64_t(asU(w1.w)) << 32);
+            if (!NEE && (didHit || meshDidHit)) {
+              const f4 w2 = wfLd(rec + 2);
+              hit.u = w2.x; hit.v = w2.y; hit.tri = asU(w2.z);
+              hit.node = asU(w2.w) & ((1u << kWfNodeBits) - 1u); hit.backSide = asU(w2.w) >> kWfNodeBits;
+            }
             for (uint32_t j = 0; j < stackIdx; j += 2u) {
-              const f4 e = wfLd(rec + 4 + (j >> 1));
+              const f4 e = wfLd(rec + 3 + (j >> 1));
               stackPoke(stk, j, uint64_t(asU(e.x)) | (uint64_t(asU(e.y)) << 32));
               if (j + 1u < stackIdx) stackPoke(stk, j + 1u, uint64_t(asU(e.z)) | (uint64_t(asU(e.w)) << 32));
             }

@@ -76,10 +76,10 @@ typedef uint64_t lds_u64;
 #endif
 // Walks the lean kernels hand to the general ones are RESUMED, not restarted (trace_lean.hpp): one record per handed-over ray.
 //   word 0: path slot, scene node, flags (bit 0 didHit, bit 1 meshDidHit, bits 8.. stack entries), link word of the leaf
-//   word 1: the leaf's entry distance, hit.t, hit.u, hit.v      word 2: hit.tri, hit.node, hit.backSide, candidate mask (low)
-//   word 3: candidate mask (high), -, -, -                        words 4..11: the traversal stack, two entries per word
+//   word 1: the leaf's entry distance, hit.t, candidate mask      word 2 (closest-hit rays that have a hit): hit.u, hit.v, hit.tri,
+//   hit.node | hit.backSide << 20                                  words 3..10: the traversal stack, two entries per word
 constexpr uint32_t kResumeStack = 16;                              // deeper stacks: the ray is restarted instead
-constexpr uint32_t kResumeWords = 4 + kResumeStack / 2;            // 16-byte words per record (192 B)
+constexpr uint32_t kResumeWords = 3 + kResumeStack / 2;            // 16-byte words per record (176 B)
 constexpr uint32_t kResumeFlag = 0x80000000u;                      // retry-queue word = record index | flag (plain word = slot: restart)
 struct TravStack {
   lds_u64* lds; uint32_t ldsStride; uint32_t ldsDepth;

@@ -224,6 +224,32 @@ def test_resumed_walks_equal_restarted_walks(api, monkeypatch):
     scene.close()
 
 
+@pytest.mark.usefixtures("oracle_bin")
+@pytest.mark.parametrize("n_instances", [9, 70])
+def test_alpha_candidates_inside_transformed_nodes_vs_oracle(api, tmp_path, n_instances):
+    """Alpha cut-out "bushes" and thin-glass panes under rotated, non-uniformly scaled, nested nodes: the rays the lean kernels
+    hand over stand inside transformed nodes, with and without an earlier hit, with some stack (9 instances: resume records;
+    70: the many-node forms of the lean kernels, which restart). Every pipeline == the oracle, bit for bit."""
+    from yart_amd import scenes
+    s, p = scenes.alpha_instances(n_instances=n_instances)
+    sp, pp, out = tmp_path / "a.yscn", tmp_path / "a.txt", tmp_path / "a.f32"
+    s.save(sp); scenes.write_params(pp, p)
+    subprocess.run([ORACLE_BIN, "render", str(sp), str(pp), str(out)], check=True, stdout=subprocess.DEVNULL)
+    scene = api.DeviceScene(s, device=0, instrumented=True)
+    ref = None
+    for name, flags in PIPELINE_FLAGS.items():
+        img, st = scene.render(p, flags=flags)
+        if ref is None:
+            ref = np.fromfile(out, np.float32).reshape(img.shape)
+        bit_identical_or_drift(img, ref, f"alpha_instances {len(s.nodes)} nodes / {name}")
+        if name == "wavefront":
+            c = scene.debug_counters()
+            assert int(c[29]) > 100 and int(c[30]) > 100, "the scene must make the lean kernels hand rays over"
+            if n_instances < 60:
+                assert int(c[8]) > 0 and int(c[9]) > 0, "resume records must have been followed"
+    scene.close()
+
+
 def _vs_oracle(api, tmp_path, s, p, tag):
     from yart_amd import scenes
     sp, pp, out = tmp_path / "e.yscn", tmp_path / "e.txt", tmp_path / "e.f32"

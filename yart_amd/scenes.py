@@ -635,6 +635,46 @@ def instances(width=96, height=96, spp=4, depth=4, n_instances=70, groups=4, see
     return s, p
 
 
+def alpha_instances(width=96, height=96, spp=4, depth=5, n_instances=9, cards=220, seed=11, tex=32):
+    """Cornell room + instances of a "bush" (`cards` small alpha cut-out quads at random in a unit cube: a tree of its own
+    ten levels deep, every leaf an alpha candidate) and of a thin-glass pane, each under a rotated, non-uniformly scaled node
+    of a translated group: rays meet alpha-tested and NEE-transparent candidates inside TRANSFORMED nodes, with and without a
+    hit found before, with traversal stacks of some depth — the cases the hand-over from the lean to the general traversal
+    kernels (resume records, trace_lean.hpp) has to carry; the opaque walls behind give closest-hit rays their earlier hits."""
+    s, p = cornell(width, height, spp, depth)
+    rng = np.random.RandomState(seed)
+    leaf_tex = s.add_texture(tex_base_color(tex, 5, (0.1, 0.35, 0.08), (0.4, 0.6, 0.2), alpha=tex_alpha_leaves(tex, 6)))
+    leaf = s.add_material(Material(base=(1, 1, 1), roughness=0.8, tex_base=leaf_tex))
+    glass = s.add_material(Material(base=(0.8, 0.9, 1.0), transmission=1.0, roughness=0.0, ior=1.5, thin_transmission=True))
+    solid = s.add_material(Material(base=(0.7, 0.3, 0.2), roughness=0.6))
+    b = MeshBuilder()
+    for _ in range(cards):
+        c = rng.uniform(-0.5, 0.5, 3)
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        v = np.cross(u, rng.normal(size=3)); v /= np.linalg.norm(v)
+        h = rng.uniform(0.06, 0.16)
+        b.quad(c - h * u - h * v, c + h * u - h * v, c + h * u + h * v, c - h * u + h * v, leaf, uv_scale=1.0)
+    b.box((-0.12, -0.5, -0.12), (0.12, 0.1, 0.12), solid)          # a trunk: opaque hits inside the same tree
+    bush = s.add_mesh(b.build())
+    g = MeshBuilder()
+    g.quad((-0.5, -0.5, 0.0), (0.5, -0.5, 0.0), (0.5, 0.5, 0.0), (-0.5, 0.5, 0.0), glass)
+    pane = s.add_mesh(g.build())
+
+    def xf(t, ry, rx, sc):
+        cy, sy, cx, sx = math.cos(ry), math.sin(ry), math.cos(rx), math.sin(rx)
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]); Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        m = np.eye(4); m[:3, :3] = Ry @ Rx @ np.diag(sc); m[:3, 3] = t
+        return m.astype(np.float32), np.linalg.inv(m).astype(np.float32)
+    f, i = xf((0.3, 0.0, -0.4), 0.35, 0.0, (1.0, 1.0, 1.0))
+    group = s.add_node(-1, 0, f, i)
+    for k in range(n_instances):
+        t = (rng.uniform(-3.0, 3.0), rng.uniform(0.8, 4.5), rng.uniform(-3.0, 2.5))
+        f2, i2 = xf(t, rng.uniform(0, 6.28), rng.uniform(-0.6, 0.6), tuple(rng.uniform(0.9, 2.2, 3)))
+        s.add_node(pane if k % 4 == 3 else bush, group, f2, i2)
+    s.create_area_lights()
+    return s, p
+
+
 def stacked_leaves(width=96, height=96, spp=4, depth=4, stacks=(40, 32, 64, 31, 33)):
     """Cornell room + cards made of `n` coincident copies of the same two triangles (n from `stacks`), the
     copies cycling through four materials. Every copy of a triangle has the same centroid, so the reference's

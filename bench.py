@@ -477,8 +477,8 @@ def main():
             e = {"kernel": k, "bound": "l2", "peak": L2_PEAK_GBPS, "avg_launch_ms": round(t_l * 1e3, 3), "launches_per_step": n_l,
                  "model": "(32 B x box tests + 52 B x triangle tests + 48 B) per ray (SURVEY §8(d) B_traversal); the BVH is cache "
                           "resident, so the roof is the L2's bandwidth, not HBM's",
-                 "note": "bound by the latency of the walk's dependent fetches at 7 waves per SIMD (72 registers, LDS stacks): 16 % fewer VALU "
-                         "instructions per step buy 1 %, 38 % fewer L1 requests 0-2 %, 4 waves cost 13 % (profiles/r3_ab_top_cache.txt); "
+                 "note": "instruction issue, L1 requests and rays in flight are in balance, none alone is the bound: 16 % fewer VALU "
+                         "instructions per step buy 1 %, 38 % fewer L1 requests 0-2 %, 4 instead of 7 waves cost 13 % (profiles/r3_ab_top_cache.txt); "
                          "TA busy 0.84, VALU issuing ~0.7 of the time (profiles/r3_mem_path_counters.txt, r3_pmc_sq_summary.txt)",
                  "kernel_tally_bytes_per_launch": int(own / n_l),
                  "kernel_tally_per_ray": {"box": round(box / max(1, trav), 2), "tri": round(tri / max(1, trav), 2)},

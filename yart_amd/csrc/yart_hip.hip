@@ -648,7 +648,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     if (!(p.flags & YART_FLAG_NO_RESUME)) {
       // (+ one range of 64 per wave of the largest grid: a wave takes its records 64 at a time and may leave a range unfinished)
       size_t cap = std::max<size_t>(np / 8, std::min<size_t>(np, 1u << 16)) + size_t(gridMax) * kBlock;
-      if (const char* e = std::getenv("YART_RESUME_CAP")) cap = size_t(std::atoll(e));
+      if (const char* e = std::getenv("YART_RESUME_CAP")) cap = size_t(std::max<long long>(0, std::atoll(e)));
       cap = std::min<size_t>(cap, 0x7fffff00u);
       if (cap) s.resumeRec.ensure(cap * kResumeWords);
       resumeCap = uint32_t(cap);

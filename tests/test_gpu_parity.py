@@ -337,7 +337,9 @@ def test_full_size_properties(api):
       * partition: the frames of 8 tile-sharded ranks are disjoint and sum to the full frame, bit for bit;
       * linearity in exposure: +1 EV scales every sample by exactly 2 before GMoN, and GMoN (sums, sort
         by luma, Gini, trimmed mean) commutes with a power-of-two scale, so the frame doubles exactly;
-      * every pixel finite with alpha 1."""
+      * every pixel finite with alpha 1;
+      * hand-overs: the frame with the lean kernels' hand-overs resumed (the default: ~150 M resume records in this frame) equals the
+        frame with every hand-over traced again from the root."""
     from yart_amd import scenes
     s, p = scenes.sponza_class(1920, 1080, 256, 8, tex=256, sky=512)
     scene = api.DeviceScene(s, device=0)
@@ -346,6 +348,8 @@ def test_full_size_properties(api):
     assert st["samples"] == 1920 * 1080 * 256
     again, _ = scene.render(p)
     assert np.array_equal(full.view(np.uint32), again.view(np.uint32))
+    restarted, st_r = scene.render(p, flags=PIPELINE_FLAGS["wavefront+no_resume"])
+    assert np.array_equal(full.view(np.uint32), restarted.view(np.uint32)) and st_r["rays"] == st["rays"]
     acc = np.zeros_like(full)
     covered = np.zeros(full.shape[:2], np.int32)
     for r in range(8):

@@ -171,16 +171,32 @@ YART_HD float trilerp8(const float* x, float u, float v, float w) {    // math_b
 }
 // The interpolated lookups read the footprint copies of the tables (LutDev::fp*: the values of one lookup side by side):
 // the same floats in the same formula, one or two 16-byte loads instead of 2-8 scattered ones.
+// A kernel may hand these functions a copy of the PLAIN tables of the glossy lobes (E, Eavg, baseE, baseEavg: the first
+// LutDev::glassE floats) in LDS instead (k_wf_shade): a lookup is then 2-8 four-byte LDS reads — a fifth of the latency of an L2
+// hit, and these lookups sit in the chain of dependent reads that kernel waits on. The pointer says which it is; behind the LDS
+// copy lies the address of the tables in memory, for the glass lobes' lookups.
+YART_HD bool lutInLds(const float* lut) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_is_shared(lut);
+#else
+  (void)lut; return false;
+#endif
+}
 YART_HD float ggxE(const float* lut, float cosTheta, float r) {        // luts.hpp:33-44
   float ro = r * 31.0f, co = cosTheta * 31.0f;
   uint32_t ri = sizeTClamp(ro, 30), ci = sizeTClamp(co, 30);
   ro -= float(ri); co -= float(ci);
+  if (lutInLds(lut)) {
+    const float* E = lut + LutDev::E + ri * 32 + ci;
+    return bilerp1(E[0], E[1], E[32], E[33], ro, co);
+  }
   const f4 e = *reinterpret_cast<const f4*>(lut + LutDev::fpE + (ri * 32 + ci) * 4);   // d00, d01, d10, d11
   return bilerp1(e.x, e.y, e.z, e.w, ro, co);
 }
 YART_HD float ggxEavg(const float* lut, float r) {                     // luts.hpp:52-57
   uint32_t ri = sizeTClamp(r * 31.0f, 30);
   float ro = r * 31.0f - float(ri);
+  if (lutInLds(lut)) return lerpf(lut[LutDev::Eavg + ri], lut[LutDev::Eavg + ri + 1], ro);
   const f2 t = *reinterpret_cast<const f2*>(lut + LutDev::fpEavg + ri * 4);
   return lerpf(t.x, t.y, ro);
 }
@@ -188,6 +204,11 @@ YART_HD float ggxBaseE(const float* lut, float f0, float r, float cosTheta) {   
   float f0o = f0 * 15.0f, ro = r * 15.0f, co = cosTheta * 15.0f;
   uint32_t f0i = sizeTClamp(f0o, 14), ri = sizeTClamp(ro, 14), ci = sizeTClamp(co, 14);
   f0o -= float(f0i); ro -= float(ri); co -= float(ci);
+  if (lutInLds(lut)) {
+    const float* B = lut + LutDev::baseE + (f0i * 16 + ri) * 16 + ci;      // [a][b][c] at a * 256 + b * 16 + c
+    const float vals[8] = {B[0], B[1], B[16], B[17], B[256], B[257], B[272], B[273]};
+    return trilerp8(vals, f0o, ro, co);
+  }
   const f4* T = reinterpret_cast<const f4*>(lut + LutDev::fpBaseE + ((f0i * 16 + ri) * 16 + ci) * 8);
   const f4 lo = T[0], hi = T[1];
   const float vals[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -196,10 +217,19 @@ YART_HD float ggxBaseE(const float* lut, float f0, float r, float cosTheta) {   
 YART_HD float ggxBaseEavg(const float* lut, float f0, float r) {       // luts.hpp:106-116
   uint32_t f0i = sizeTClamp(f0 * 15.0f, 14), ri = sizeTClamp(r * 15.0f, 14);
   float f0o = f0 * 15.0f - float(f0i), ro = r * 15.0f - float(ri);
+  if (lutInLds(lut)) {
+    const float* A = lut + LutDev::baseEavg + f0i * 16 + ri;
+    return bilerp1(A[0], A[1], A[16], A[17], f0o, ro);
+  }
   const f4 t = *reinterpret_cast<const f4*>(lut + LutDev::fpBaseEavg + (f0i * 16 + ri) * 4);
   return bilerp1(t.x, t.y, t.z, t.w, f0o, ro);
 }
 YART_HD float ggxGlassE(const float* lut, float ior, float r, float cosTheta) {   // luts.hpp:126-158
+  if (lutInLds(lut)) {                                          // the glass tables are not in the LDS copy: their address lies behind it
+    uint64_t p; const uint32_t* w = reinterpret_cast<const uint32_t*>(lut + LutDev::glassE);
+    p = uint64_t(w[0]) | (uint64_t(w[1]) << 32);
+    lut = reinterpret_cast<const float*>(p);
+  }
   bool inv = ior < 1.0f;
   if (inv) ior = 1.0f / ior;
   float f0 = sqrtf(fabsf((1.0f - ior) / (1.0f + ior)));

@@ -202,7 +202,7 @@ struct SceneDev {
   const float* lut;                 // LutDev layout
   uint32_t nNodes, nLights, nInfinite, nArea;
   float totalPower;
-  uint32_t pad[3];
+  uint32_t nMaterials, nTextures, nEnvs;   // sizes of the (padded) record arrays: what a kernel copies when it keeps them in LDS
 };
 
 struct Hit {                   // cpu/hit.hpp:8-17 after testNode returned

@@ -498,9 +498,9 @@ RenderConst makeRenderConst(const YartRenderParams& p) {
   return rc;
 }
 
-int persistentGrid(const YartScene& s, const void* kernel, int cap) {
+int persistentGrid(const YartScene& s, const void* kernel, int cap, int block = kBlock) {
   int perCU = 0;
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlock, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, block, 0));
   if (perCU < 1) perCU = 1;
   if (perCU > cap) perCU = cap;
   return s.numCUs * perCU;
@@ -592,7 +592,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend<false>), 8);
   const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow<false>), 8);
   auto kShade = (effFlags & YART_FLAG_SHADE_SORT) ? k_wf_shade<true> : k_wf_shade<false>;
-  const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(kShade), 8);
+  const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(kShade), 8, kShadeBlock);
   const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(kRetryE), 8);
   const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(kRetryS), 8);
   int gridMax = std::max(gridMega, std::max(gridExtend, gridShadow));
@@ -751,7 +751,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           tExtend.end(stream);
           tShade.begin(stream);
           tShadeK.begin(stream);
-          hipLaunchKernelGGL(kShade, dim3(gridShade), dim3(kBlock), 0, stream, a);
+          hipLaunchKernelGGL(kShade, dim3(gridShade), dim3(kShadeBlock), 0, stream, a);
           HIP_CHECK(hipGetLastError());
           tShadeK.end(stream);
           tShade.end(stream);

@@ -77,7 +77,7 @@ struct HostImage {
     s.tlas = tlas.data(); s.nTlas = uint32_t(tlas.size()); s.nodeBits = nullptr; s.nodeBitWords = 0;
     s.infiniteLights = infiniteLights.data(); s.areaLights = areaLights.data();
     s.areaPowerCdf = areaPowerCdf.data(); s.lut = lut.data();
-    s.nMaterials = uint32_t(materials.size()); s.nTextures = uint32_t(textures.size()); s.nEnvs = uint32_t(envs.size());
+    s.nMeshes = uint32_t(meshes.size()); s.nMaterials = uint32_t(materials.size()); s.nTextures = uint32_t(textures.size()); s.nEnvs = uint32_t(envs.size());
     s.nNodes = uint32_t(nodes.size()); s.nLights = nLights;
     s.nInfinite = nInfinite; s.nArea = nArea;
     s.totalPower = totalPower;

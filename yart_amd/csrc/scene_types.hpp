@@ -202,6 +202,7 @@ struct SceneDev {
   const float* lut;                 // LutDev layout
   uint32_t nNodes, nLights, nInfinite, nArea;
   float totalPower;
+  uint32_t nMeshes;
   uint32_t nMaterials, nTextures, nEnvs;   // sizes of the (padded) record arrays: what a kernel copies when it keeps them in LDS
 };
 

@@ -250,6 +250,27 @@ def test_alpha_candidates_inside_transformed_nodes_vs_oracle(api, tmp_path, n_in
     scene.close()
 
 
+@pytest.mark.usefixtures("oracle_bin")
+def test_tables_larger_than_their_lds_slots_vs_oracle(api, tmp_path):
+    """The shade kernel keeps the scene's small record tables in LDS where they fit (materials <= 64, texture descriptors <= 128,
+    lights <= 8, ...); this scene has 96 materials, 160 textures and 26 area lights: every table stays in memory, and every
+    pipeline must still reproduce the oracle bit for bit (scenes.many_records)."""
+    from yart_amd import scenes
+    s, p = scenes.many_records()
+    assert len(s.materials) > 64 and len(s.textures) > 128 and len(s.lights) > 8
+    sp, pp, out = tmp_path / "m.yscn", tmp_path / "m.txt", tmp_path / "m.f32"
+    s.save(sp); scenes.write_params(pp, p)
+    subprocess.run([ORACLE_BIN, "render", str(sp), str(pp), str(out)], check=True, stdout=subprocess.DEVNULL)
+    scene = api.DeviceScene(s, device=0)
+    ref = None
+    for name, flags in PIPELINE_FLAGS.items():
+        img, st = scene.render(p, flags=flags)
+        if ref is None:
+            ref = np.fromfile(out, np.float32).reshape(img.shape)
+        bit_identical_or_drift(img, ref, f"many_records / {name}")
+    scene.close()
+
+
 def _vs_oracle(api, tmp_path, s, p, tag):
     from yart_amd import scenes
     sp, pp, out = tmp_path / "e.yscn", tmp_path / "e.txt", tmp_path / "e.f32"

@@ -675,6 +675,31 @@ def alpha_instances(width=96, height=96, spp=4, depth=5, n_instances=9, cards=22
     return s, p
 
 
+def many_records(width=96, height=96, spp=4, depth=5, n_materials=80, n_lights=12, seed=3, tex=32):
+    """Cornell room + a wall of `n_materials` small tiles, each with a material and a base-colour texture of its own (metal / rough /
+    clearcoat mixes), and `n_lights` small emissive quads (two area lights each): more materials (> 64), texture descriptors (> 128
+    with the walls') and lights (> 8) than the slots of the LDS copies the shade kernel keeps of these tables (wavefront_kernels.inc)
+    — the tables then stay in memory, and the frame must not change."""
+    s, p = cornell(width, height, spp, depth)
+    rng = np.random.RandomState(seed)
+    b = MeshBuilder()
+    cols = 10
+    for k in range(n_materials):
+        t = s.add_texture(tex_base_color(tex, 100 + k, tuple(rng.uniform(0.1, 0.5, 3)), tuple(rng.uniform(0.5, 0.95, 3))))
+        t2 = s.add_texture(tex_metal_rough(tex, 300 + k, (0.2, 0.9), (0.0, 1.0)))
+        m = s.add_material(Material(base=(1, 1, 1), roughness=float(rng.uniform(0.15, 1.0)), metallic=float(rng.rand() > 0.6),
+                                    clearcoat=float(rng.rand() > 0.8), tex_base=t, tex_mr=t2 if k % 3 == 0 else -1))
+        x0 = -4.5 + 0.9 * (k % cols); y0 = 0.6 + 0.9 * (k // cols)
+        b.quad((x0, y0, -4.6), (x0 + 0.8, y0, -4.6), (x0 + 0.8, y0 + 0.8, -4.55), (x0, y0 + 0.8, -4.55), m, uv_scale=1.0)
+    for k in range(n_lights):
+        e = s.add_material(Material(base=(0.8, 0.8, 0.8), roughness=1.0, emission=tuple(rng.uniform(2.0, 9.0, 3))))
+        x0 = -4.2 + 0.7 * k
+        b.quad((x0, 9.9, 1.0), (x0 + 0.4, 9.9, 1.0), (x0 + 0.4, 9.9, 1.5), (x0, 9.9, 1.5), e)
+    s.add_node(s.add_mesh(b.build()))
+    s.create_area_lights()
+    return s, p
+
+
 def stacked_leaves(width=96, height=96, spp=4, depth=4, stacks=(40, 32, 64, 31, 33)):
     """Cornell room + cards made of `n` coincident copies of the same two triangles (n from `stacks`), the
     copies cycling through four materials. Every copy of a triangle has the same centroid, so the reference's

@@ -67,8 +67,8 @@ constexpr int kShadeRegions = 16;
 __device__ unsigned long long g_shadeRegion[3 * kShadeRegions];   // [k] cycles, [16 + k] visits, [32 + k] lanes
 #endif
 #if defined(YART_SHADE_REGIONS) && defined(__HIP_DEVICE_COMPILE__)
-__shared__ unsigned long long srAcc[4][3 * kShadeRegions];
-__shared__ unsigned long long srLast[4];
+__shared__ unsigned long long srAcc[16][3 * kShadeRegions];    // (one row per wave of the workgroup: the shade kernel runs 12)
+__shared__ unsigned long long srLast[16];
 #define SR_MARK(k)                                                                       \
   do {                                                                                   \
     const unsigned long long _m = __ballot(true);                                        \

@@ -374,6 +374,7 @@ void uploadScene(YartScene& s) {
   {
     std::vector<uint8_t> cls;
     for (const MaterialDev& m : h.materials) cls.push_back(lobeClass(m));
+    while (cls.size() % 4u) cls.push_back(0);          // (the shade kernel copies the classes into LDS a word at a time)
     s.matClass.upload(cls);
   }
   // the textures' 2x2 footprint records: expanded here from the plain texel arrays just uploaded

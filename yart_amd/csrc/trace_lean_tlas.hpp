@@ -241,7 +241,8 @@ __device__ __forceinline__ void traceLeanTlas(const SceneDev& sc, const SamplerC
 #endif
 }
 
-// the kernels' entry: NODES 0 = one candidate mask (fewer than 64 nodes), 1 = chunked masks, 2 = per-lane walk, 3 = windows from the top-level hierarchy
+// the kernels' entry: NODES 0 = one candidate mask (fewer than 64 nodes), 4 = the same with the scene walk's tables in LDS (at most 16 nodes and meshes: the kernels copy
+// them), 1 = chunked masks, 2 = per-lane walk, 3 = windows from the top-level hierarchy
 template <bool NEE, int MODE, int NODES, class Fetch, class Commit, class Retry>
 __device__ __forceinline__ void traceLeanAny(const SceneDev& sc, const SamplerConfig& scfg, const TravStack& stk,
                                              const uint32_t* queue, uint32_t count, uint32_t* cursor,

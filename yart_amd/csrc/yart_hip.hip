@@ -569,9 +569,11 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // nodes, profiles/r2_many_nodes.txt). Without it (no mesh nodes, more than 16384 nodes = 2 KB of bitset per lane, or debug bit
   // 262144): chunked masks below kLeanWalkNodes nodes, the per-lane walk from there on (debug bit 65536: the walk at any size)
   const bool tlasOk = s.dev.nTlas != 0u && s.host.nodes.size() <= 16384u && !(effFlags & (262144u | 65536u));
-  const int nodesForm = !chunked ? 0 : tlasOk ? 3 : ((effFlags & 65536u) || s.host.nodes.size() >= kLeanWalkNodes) ? 2 : 1;
+  const bool leanLds = !chunked && s.host.nodes.size() <= kLeanSceneNodes && s.host.meshes.size() <= kLeanSceneNodes;
+  const int nodesForm = !chunked ? (leanLds ? 4 : 0) : tlasOk ? 3 : ((effFlags & 65536u) || s.host.nodes.size() >= kLeanWalkNodes) ? 2 : 1;
 #define YART_PICK_LEAN(KERNEL, M)                                                                                             \
-  (nodesForm == 3 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 3> : KERNEL<(M), 3>)                                                 \
+  (nodesForm == 4 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 4> : KERNEL<(M), 4>)                                                 \
+   : nodesForm == 3 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 3> : KERNEL<(M), 3>)                                               \
    : nodesForm == 2 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 2> : KERNEL<(M), 2>)                                               \
    : nodesForm == 1 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 1> : KERNEL<(M), 1>) : (ident ? KERNEL<(M) | TRAV_IDENTITY, 0> : KERNEL<(M), 0>))
   auto pickExtend = [&]() -> void (*)(WfArgs) {
@@ -585,14 +587,19 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
 #undef YART_PICK_LEAN
   auto kExtendFast = pickExtend();
   auto kShadowFast = pickShadow();
-  auto kRetryE = nodesForm == 3 ? k_wf_extend_retry_lean<3> : nodesForm == 2 ? k_wf_extend_retry_lean<2> : nodesForm == 1 ? k_wf_extend_retry_lean<1> : k_wf_extend_retry_lean<0>;
-  auto kRetryS = nodesForm == 3 ? k_wf_shadow_retry_lean<3> : nodesForm == 2 ? k_wf_shadow_retry_lean<2> : nodesForm == 1 ? k_wf_shadow_retry_lean<1> : k_wf_shadow_retry_lean<0>;
+  auto kRetryE = nodesForm == 4 ? k_wf_extend_retry_lean<4> : nodesForm == 3 ? k_wf_extend_retry_lean<3> : nodesForm == 2 ? k_wf_extend_retry_lean<2> : nodesForm == 1 ? k_wf_extend_retry_lean<1> : k_wf_extend_retry_lean<0>;
+  auto kRetryS = nodesForm == 4 ? k_wf_shadow_retry_lean<4> : nodesForm == 3 ? k_wf_shadow_retry_lean<3> : nodesForm == 2 ? k_wf_shadow_retry_lean<2> : nodesForm == 1 ? k_wf_shadow_retry_lean<1> : k_wf_shadow_retry_lean<0>;
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
   const int gridExtendFast = persistentGrid(s, reinterpret_cast<const void*>(kExtendFast), 8);
   const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);
   const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend<false>), 8);
   const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow<false>), 8);
-  auto kShade = (effFlags & YART_FLAG_SHADE_SORT) ? k_wf_shade<true> : k_wf_shade<false>;
+  // the shade kernel's LDS copies of the scene's small tables: FIT when the sampler tables are in use (below) and every table fits its slot
+  const bool samplerTables = !mega && !(p.flags & YART_FLAG_DIRECT_SAMPLER) && nPix > 0 && uint64_t(p.samples) <= (1ull << rc.sampler.log2spp);
+  const bool shadeFit = samplerTables && s.dev.nMaterials <= kShadeMatSlots && s.dev.nTextures <= kShadeTexSlots && s.dev.nLights <= kShadeLightSlots &&
+                        s.dev.nEnvs <= kShadeEnvSlots && s.dev.nNodes <= kShadeNodeSlots && s.dev.nInfinite <= kShadeLightSlots;
+  auto kShade = (effFlags & YART_FLAG_SHADE_SORT) ? (shadeFit ? k_wf_shade<true, true> : k_wf_shade<true, false>)
+                                                  : (shadeFit ? k_wf_shade<false, true> : k_wf_shade<false, false>);
   const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(kShade), 8, kShadeBlock);
   const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(kRetryE), 8);
   const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(kRetryS), 8);
@@ -665,8 +672,8 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // sampler tables (sampler.hpp::SamplerTables) for the wavefront pipeline; they require every
   // sample index to fit the sampler's log2spp bits (log2Int rounds to nearest, e.g. 90 spp -> 6)
   RenderConst rcw = rc;
-  if (!mega && !(p.flags & YART_FLAG_DIRECT_SAMPLER) && nPix > 0 && uint64_t(p.samples) <= (1ull << rc.sampler.log2spp)) {
-    const uint32_t dims = std::min<uint32_t>(256u, (4u + 8u * p.max_depth + 16u + 7u) & ~7u);
+  if (samplerTables) {
+    const uint32_t dims = std::min<uint32_t>(256u, (4u + 8u * p.max_depth + 16u + 7u) & ~7u);     // (+ 3 <= kShadeHashSlots)
     s.smpEntries.ensure(size_t(dims) * nPix); s.smpHash.ensure(dims + 3); s.smpSobol1.ensure(8 * 256);
     SamplerTabArgs ta{};
     ta.cfg = rc.sampler; ta.pixels = s.pixels.p; ta.nPixels = nPix; ta.dims = dims;

@@ -107,16 +107,21 @@ YART_HD f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z
 // Streaming access to the path state: every word is read / written once per kernel, so it is marked
 // non-temporal to keep it from displacing BVH nodes, leaf records and textures in L2.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(YART_NO_NT_STATE)
+// The state pointers reach the kernels through a struct argument and, with compaction, out of memory (WF_DYN): the compiler does not know
+// what they point to and would use flat loads / stores, which count on the vector-memory AND the LDS counter (a wait for either waits for
+// both). Everything these three helpers touch — path state, per-sample radiance, resume records — is global memory, and they say so.
 typedef float wf_v4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) wf_v4 wf_v4_global;
+typedef __attribute__((address_space(1))) float wf_f_global;
 __device__ __forceinline__ f4 wfLd(const f4* p) {
-  const wf_v4 v = __builtin_nontemporal_load(reinterpret_cast<const wf_v4*>(p));
+  const wf_v4 v = __builtin_nontemporal_load((const wf_v4_global*) reinterpret_cast<const wf_v4*>(p));
   return mk4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void wfSt(f4* p, f4 v) {
   wf_v4 q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
-  __builtin_nontemporal_store(q, reinterpret_cast<wf_v4*>(p));
+  __builtin_nontemporal_store(q, (wf_v4_global*) reinterpret_cast<wf_v4*>(p));
 }
-__device__ __forceinline__ void wfSt1(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void wfSt1(float* p, float v) { __builtin_nontemporal_store(v, (wf_f_global*) p); }
 #else
 YART_HD f4 wfLd(const f4* p) { return *p; }
 YART_HD void wfSt(f4* p, f4 v) { *p = v; }

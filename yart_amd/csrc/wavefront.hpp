@@ -122,10 +122,12 @@ __device__ __forceinline__ void wfSt(f4* p, f4 v) {
   __builtin_nontemporal_store(q, (wf_v4_global*) reinterpret_cast<wf_v4*>(p));
 }
 __device__ __forceinline__ void wfSt1(float* p, float v) { __builtin_nontemporal_store(v, (wf_f_global*) p); }
+__device__ __forceinline__ float wfLd1(const float* p) { return *(const wf_f_global*) p; }     // (a word that is read again soon: cached)
 #else
 YART_HD f4 wfLd(const f4* p) { return *p; }
 YART_HD void wfSt(f4* p, f4 v) { *p = v; }
 YART_HD void wfSt1(float* p, float v) { *p = v; }
+YART_HD float wfLd1(const float* p) { return *p; }
 #endif
 
 struct WfPath {             // register image of one path

@@ -598,8 +598,10 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const bool samplerTables = !mega && !(p.flags & YART_FLAG_DIRECT_SAMPLER) && nPix > 0 && uint64_t(p.samples) <= (1ull << rc.sampler.log2spp);
   const bool shadeFit = samplerTables && s.dev.nMaterials <= kShadeMatSlots && s.dev.nTextures <= kShadeTexSlots && s.dev.nLights <= kShadeLightSlots &&
                         s.dev.nEnvs <= kShadeEnvSlots && s.dev.nNodes <= kShadeNodeSlots && s.dev.nInfinite <= kShadeLightSlots;
-  auto kShade = (effFlags & YART_FLAG_SHADE_SORT) ? (shadeFit ? k_wf_shade<true, true> : k_wf_shade<true, false>)
-                                                  : (shadeFit ? k_wf_shade<false, true> : k_wf_shade<false, false>);
+  const bool envOnly = shadeFit && s.dev.nArea == 0u && s.dev.nInfinite == 1u && s.dev.nLights == 1u;    // (variant of the FIT kernels only)
+  auto kShade = (effFlags & YART_FLAG_SHADE_SORT)
+                    ? (envOnly ? k_wf_shade<true, true, true> : shadeFit ? k_wf_shade<true, true, false> : k_wf_shade<true, false, false>)
+                    : (envOnly ? k_wf_shade<false, true, true> : shadeFit ? k_wf_shade<false, true, false> : k_wf_shade<false, false, false>);
   const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(kShade), 8, kShadeBlock);
   const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(kRetryE), 8);
   const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(kRetryS), 8);

@@ -31,18 +31,23 @@ struct Error : std::runtime_error {
   Error(int c, const char* msg) : std::runtime_error(std::string("yart_hip: ") + msg), code(c) {}
 };
 inline void check(int rc) { if (rc != YART_OK) throw Error(rc, yart_hip_last_error()); }
+// the loaded library must speak the ABI these wrappers were compiled against (struct layouts, flag values)
+inline void requireAbi() {
+  if (yart_hip_abi_version() != YART_HIP_ABI_VERSION) throw Error(YART_E_INVALID, "libyart_hip.so and yart_hip.h disagree on YART_HIP_ABI_VERSION");
+}
 
 // Owns a device-resident scene (flattened geometry, BVHs, materials, lights).
 class DeviceScene {
  public:
-  explicit DeviceScene(const YartSceneDesc& desc, int device = -1) { check(yart_hip_scene_create(&desc, device, &h_)); }
-  explicit DeviceScene(const std::string& yscnPath, int device = -1) { check(yart_hip_scene_load(yscnPath.c_str(), device, &h_)); }
+  explicit DeviceScene(const YartSceneDesc& desc, int device = -1) { requireAbi(); check(yart_hip_scene_create(&desc, device, &h_)); }
+  explicit DeviceScene(const std::string& yscnPath, int device = -1) { requireAbi(); check(yart_hip_scene_load(yscnPath.c_str(), device, &h_)); }
   // a glTF 2.0 / GLB asset, as gltf::load + the frontend's environment light (src/gltf/gltf.cpp:319-358, src/main.cpp:78-86)
   static DeviceScene fromGltf(const std::string& path, const std::string& envHdrPath = "", float envRadius = 100.0f, int device = -1) {
     YartImportOptions o{};
     o.env_hdr_path = envHdrPath.empty() ? nullptr : envHdrPath.c_str();
     o.env_radius = envRadius;
     YartScene* h = nullptr;
+    requireAbi();
     check(yart_hip_scene_load_gltf(path.c_str(), &o, device, &h));
     return DeviceScene(h);
   }

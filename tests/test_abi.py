@@ -21,7 +21,7 @@ def test_exports_match_header(built):
     assert set(names) == set(api.EXPORTS)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.yart_hip_abi_version() == 2
+    assert lib.yart_hip_abi_version() == 3
 
 
 def test_struct_sizes_match_file_records(built):

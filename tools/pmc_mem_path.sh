@@ -1,6 +1,6 @@
 #!/bin/bash
 # Address-path counters of the large kernels over one un-timed step of the bench workload: texture-addresser busy cycles, L1 (TCP)
-# accesses / stalls, address-translation (UTCL1) misses. usage (GPU box): tools/pmc_mem_path.sh TAG -> gpurun_out/TAG_mem_path.txt
+# accesses / stalls, address-translation (UTCL1) misses. usage (GPU box): tools/pmc_mem_path.sh TAG [FLAGS] -> gpurun_out/TAG_mem_path.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=${1:-r3}
 # (at most two counters of a block per pass: the TA / TCP blocks have few slots; every pass under its own timeout, progress printed)
@@ -10,7 +10,7 @@ i=0
 for ctrs in "${PASSES[@]}"; do
   i=$((i+1))
   echo "pass $i: $ctrs"
-  timeout -k 10 150 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_mp_$i -o run -- python3 $R/tools/pmc_run.py 0 1920 1080 16 > $R/gpurun_out/${TAG}_mp_$i.log 2>&1 || { echo "pass $i failed"; grep -m2 -i "error\|exceeds" $R/gpurun_out/${TAG}_mp_$i.log | cut -c1-200; }
+  timeout -k 10 150 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_mp_$i -o run -- python3 $R/tools/pmc_run.py ${2:-0} 1920 1080 16 > $R/gpurun_out/${TAG}_mp_$i.log 2>&1 || { echo "pass $i failed"; grep -m2 -i "error\|exceeds" $R/gpurun_out/${TAG}_mp_$i.log | cut -c1-200; }
 done
 python3 - <<PY > $R/gpurun_out/${TAG}_mem_path.txt
 import csv, glob, collections, sys

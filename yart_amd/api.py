@@ -31,6 +31,7 @@ if os.environ.get("YART_LIB_VARIANT"):      # experiment builds of tools/build_v
     LIB_PATH = os.path.join(_HERE, "_variants", os.environ["YART_LIB_VARIANT"] + ".so")
 
 YART_OK, YART_E_INVALID, YART_E_NO_DEVICE, YART_E_HIP, YART_E_IO, YART_E_RCCL = 0, -1, -2, -3, -4, -5
+ABI_VERSION = 3          # include/yart_hip.h: YART_HIP_ABI_VERSION (struct layouts below)
 FLAG_MEGAKERNEL = 1
 FLAG_SHADE_SORT = 2
 FLAG_GENERAL_TRACE = 4
@@ -39,6 +40,7 @@ FLAG_NO_REFILL = 16
 FLAG_NO_COMPACTION = 32
 FLAG_NO_SHADE_SORT = 64
 FLAG_NO_RESUME = 128
+FLAG_WIDE_TREES = 256
 
 
 class YartError(RuntimeError):
@@ -105,6 +107,10 @@ class RenderParams(C.Structure):
                 ("estimator", C.c_uint32), ("shard_tile", C.c_uint32), ("max_batch_paths", C.c_uint32)]
 
 
+def _plain(v):
+    return list(v) if hasattr(v, "__len__") else v
+
+
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("ms_total", C.c_double),
                 ("ms_device", C.c_double), ("ms_traverse", C.c_double), ("traversals", C.c_uint64),
@@ -119,10 +125,13 @@ class Stats(C.Structure):
                 ("shadow_lean_traversals", C.c_uint64), ("shadow_lean_box_tests", C.c_uint64),
                 ("shadow_lean_tri_tests", C.c_uint64), ("shade_entries", C.c_uint64),
                 ("texture_tap_bytes", C.c_uint64), ("pipeline_flags", C.c_uint32), ("reserved1", C.c_uint32),
-                ("retry_extend_traversals", C.c_uint64), ("retry_shadow_traversals", C.c_uint64)]
+                ("retry_extend_traversals", C.c_uint64), ("retry_shadow_traversals", C.c_uint64),
+                ("wide_extend_nodes", C.c_uint64), ("wide_extend_tris", C.c_uint64),
+                ("wide_shadow_nodes", C.c_uint64), ("wide_shadow_tris", C.c_uint64),
+                ("wide_extend_handed", C.c_uint64 * 4), ("wide_shadow_handed", C.c_uint64 * 4)]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: _plain(getattr(self, k)) for k, _ in self._fields_}
 
 
 # YartRenderParams.estimator (core/estimator.hpp; the reference picks one at compile time, integrator.cpp:17-18)
@@ -199,6 +208,9 @@ def lib(instrumented: bool = False):
             raise YartError(YART_E_NO_DEVICE, f"{path} not built (run __graft_entry__.build()); "
                                               "there is no CPU fallback")
         L = C.CDLL(path)
+        if L.yart_hip_abi_version() != ABI_VERSION:
+            raise YartError(YART_E_INVALID, f"{path} has ABI {L.yart_hip_abi_version()}, this module binds ABI {ABI_VERSION} "
+                                            "(include/yart_hip.h: YART_HIP_ABI_VERSION); rebuild the library")
         L.yart_hip_last_error.restype = C.c_char_p
         L.yart_hip_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.yart_hip_scene_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]

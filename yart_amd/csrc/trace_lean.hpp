@@ -18,6 +18,7 @@
 #pragma once
 #if defined(__HIPCC__)
 #include "traverse.hpp"
+#include "traverse_wide.hpp"
 
 namespace yart_hip {
 
@@ -33,6 +34,16 @@ constexpr uint32_t kLeanRefill = YART_LEAN_REFILL;      // refill when at least 
 #define YART_LEAN_INNER_MIN 12
 #endif
 constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;
+// the same two thresholds for the kernels that walk their own 8-wide trees (a node step there is twice a binary step)
+#ifndef YART_WIDE_REFILL
+#define YART_WIDE_REFILL 52
+#endif
+#ifndef YART_WIDE_INNER_MIN
+#define YART_WIDE_INNER_MIN 12
+#endif
+#ifndef YART_WIDE_TRI_MIN
+#define YART_WIDE_TRI_MIN 8      // the triangle loop is left when fewer lanes than this still have triangles and others wait to step
+#endif
 #ifndef YART_LEAN_CHUNK_MAX
 #define YART_LEAN_CHUNK_MAX 256u
 #endif   // leave the inner loop when fewer lanes than this still step
@@ -54,6 +65,22 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                                           uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
                                           Retry retry, WfTally& tally) {
   constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
+  // TRAV_WIDE (lean kernels only): inside a mesh the lane walks the mesh's own 8-wide trees (trace_lean_wide.inc) instead of the
+  // reference's binary tree; rays whose result could depend on the reference's order go to the general kernel (from the root)
+  constexpr bool kWide = (MODE & TRAV_WIDE) != 0;
+  static_assert(!kWide || kFast, "TRAV_WIDE is a variant of the lean (TRAV_FAST) walk");
+  constexpr uint32_t kRefill = kWide ? uint32_t(YART_WIDE_REFILL) : kLeanRefill;      // (the names the parts below use)
+  constexpr uint32_t kInnerMin = kWide ? uint32_t(YART_WIDE_INNER_MIN) : kLeanInnerMin;
+  __shared__ uint32_t wideSpreadLds[kWide ? 256 : 1];
+  __shared__ uint8_t widePermLds[kWide ? 2048 : 4];
+  if (kWide) {
+    for (uint32_t k = threadIdx.x; k < 256u; k += blockDim.x) wideSpreadLds[k] = wideSpread(k);
+    for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x) widePermLds[k] = uint8_t(widePerm(k >> 8, k & 255u));
+    __syncthreads();
+  }
+  WideSetup ws; ws.o = mk3(0.0f); ws.idir = mk3(1.0f); ws.offX = 32u; ws.offY = 64u; ws.offZ = 96u; ws.octinv = 7u;
+  uint32_t wG = 0, wB = 0, wT = 0, wTB = 0, wTV = 0, wPhase = 1, wRootO = kNoWide;
+  bool crossedT = false;                                      // shadow ray: crossed an NEE-transparent triangle while unoccluded
   Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
   f3 attenuation = mk3(1.0f);
   const uint32_t lane = threadIdx.x & 63u;
@@ -93,7 +120,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
       // such repeats, profiles/r3_ab_top_cache.txt). Not for a shadow ray that is occluded already: from then on the lean walk
       // skips subtrees without alpha-tested triangles, which the general walk — the reference's — does not.
       uint32_t word = slot;
-      if (stk.rec != nullptr && __ballot(pendingRetry) != 0ull) {
+      if (!kWide && stk.rec != nullptr && __ballot(pendingRetry) != 0ull) {
         const bool can = pendingRetry && stackIdx <= kResumeStack && !(NEE && (didHit || meshDidHit));
         const unsigned long long mc = __ballot(can);
         const uint32_t need = uint32_t(__popcll(mc));
@@ -133,9 +160,9 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
     const uint32_t nIdle = uint32_t(__popcll(idle));
     // results of the rays that finished since the last refill are committed together, just before their lanes take new
     // rays (>= kLeanRefill lanes: what a commit loads / stores is issued for most of the wave at once, not lane by lane)
-    if ((nIdle >= kLeanRefill || exhausted) && done) { commit(slot, hit, didHit, attenuation, smp.dim); done = false; }
+    if ((nIdle >= kRefill || exhausted) && done) { commit(slot, hit, didHit, attenuation, smp.dim); done = false; }
     if (nIdle == 64u && exhausted) break;
-    if (!exhausted && nIdle >= kLeanRefill) {
+    if (!exhausted && nIdle >= kRefill) {
       // queue positions for the idle lanes: the first 64 by wave index; later ones from the wave's private range of the queue,
       // which is topped up `chunk` entries at a time from the shared cursor (one atomic per chunk, not per refill: a single L2
       // word takes ~90 atomics per microsecond, and 10 M refills per launch ran into exactly that; consecutive refills of a
@@ -174,7 +201,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
           const LeanRay r = fetch(slot);
           ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true;
           hit.t = r.tMax; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
-          has = true; inMesh = false; nodeI = 0; didHit = false;
+          has = true; inMesh = false; nodeI = 0; didHit = false; crossedT = false;
           if (!kFast) { smp = r.smp; attenuation = mk3(1.0f); }
           YART_COUNT(nTrav, 1);
 #if defined(YART_COUNT_TRAVERSAL)
@@ -220,6 +247,8 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
       const bool fresh = has && cand == ~0ull;
       if (fresh) cand = sc.nNodes >= 64u ? ~0ull : ((1ull << sc.nNodes) - 1ull);
       for (uint32_t n = 0; n < sc.nNodes; n++) {
+        // (a node no new ray of the wave can still reach — its parent's box was missed by all of them — costs a scalar branch)
+        if (__ballot(fresh && ((cand >> n) & 1ull)) == 0ull) continue;
         const f4 wlo = sc.nodeWorld[2u * n], whi = sc.nodeWorld[2u * n + 1u];
         if (fresh && ((cand >> n) & 1ull)) {
           WF_PHASE(tally, 4);                                   // candidate-mask box tests
@@ -239,7 +268,10 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
         WF_PHASE(tally, 3);                                     // walk steps
         const unsigned long long rest = nodeI < 64u ? (cand >> nodeI) : 0ull;
         if (rest == 0ull) {                                     // testNode of the root has returned
-          done = true;                                          // (committed at the next refill)
+          // (wide walk, shadow ray: an unoccluded ray that crossed an NEE-transparent triangle carries an attenuation the
+          // reference multiplies up in its order: the general kernel's)
+          if (kWide && NEE && crossedT && !didHit) pendingRetry = true;
+          else done = true;                                     // (committed at the next refill)
           has = false;
         } else {
           nodeI += uint32_t(__builtin_ctzll(rest));             // next node the ray can reach
@@ -271,8 +303,20 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                 const BvhNode root = nodes[0];
                 YART_COUNT(nBox, 1);
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
+                  if (kWide) {
+                    // tree A (alpha-tested / NEE-transparent triangles) first, then tree O; the root as a group of one
+                    if (!wideSetup(ray, mesh.wideRo, ws)) { YART_COUNT(nHand[3], 1); pendingRetry = true; has = false; }
+                    else {
+                      inMesh = true; meshDidHit = false; stackIdx = 0; wTB = 0u;
+                      wRootO = mesh.wideRootO;
+                      wPhase = mesh.wideRootA != kNoWide ? 0u : 1u;
+                      wG = (wPhase == 0u ? mesh.wideRootA : wRootO) - (7u ^ ws.octinv); wB = 0x800000ffu;
+                    }
+                    entered = true;
+                  } else {
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
+                  }
                 }
               }
             }
@@ -282,12 +326,18 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
       }
     }
 
+    if constexpr (kWide) {
+#include "trace_lean_wide.inc"
+    } else {
 #include "trace_lean_bvh2.inc"
+    }
   }
 #undef LEAN_VISIT
   (void)meshHasAlpha;
 #if defined(YART_COUNT_TRAVERSAL)
   tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav; tally.resumed += actx.nResumed;
+  tally.wideNodes += actx.nWideNodes; tally.wideTris += actx.nWideTris;
+  for (int k = 0; k < 4; k++) tally.hand[k] += actx.nHand[k];
 #else
   (void)tally;
 #endif

@@ -134,7 +134,9 @@ struct HitRec {              // what the walk tracks of cpu/hit.hpp
 //   TRAV_IDENTITY  every scene node's transform chain is the identity (checked at scene build):
 //                  no 4x4 products, the world ray (+0) is used for every node; ~30 VGPRs.
 // Together they bring the closest-hit kernel from 127 to 74 VGPRs, i.e. from 4 to 6 waves/SIMD.
-enum : int { TRAV_GENERAL = 0, TRAV_FAST = 1, TRAV_IDENTITY = 2 };
+//   TRAV_WIDE      lean kernels with in-wave replacement only (trace_lean.hpp): inside a mesh the ray walks the mesh's own
+//                  8-wide trees (bvh8_build.hpp, trace_lean_wide.inc) instead of the reference's binary tree.
+enum : int { TRAV_GENERAL = 0, TRAV_FAST = 1, TRAV_IDENTITY = 2, TRAV_WIDE = 4 };
 
 struct AlphaCtx {            // state the stochastic alpha test draws from
   Sampler* sampler;
@@ -142,6 +144,8 @@ struct AlphaCtx {            // state the stochastic alpha test draws from
   bool deferred = false;     // TRAV_FAST: the ray met an alpha / transparent candidate
 #if defined(YART_COUNT_TRAVERSAL)
   uint32_t nBox = 0, nTri = 0, nTrav = 0, nResumed = 0;
+  uint32_t nWideNodes = 0, nWideTris = 0;     // node visits / triangle tests of the 8-wide walk
+  uint32_t nHand[4] = {0, 0, 0, 0};           // its hand-overs: alpha / transparent crossing, tie, acceptance check (or NaN t), ray guard
 #endif
 };
 

@@ -205,6 +205,30 @@ def cpu_baseline(scene, p, args):
     return (entry, ref_order), frame
 
 
+def visible_gpu_count():
+    """GPUs this process could open, WITHOUT touching the HIP runtime (torch.cuda.device_count() falls back to hipGetDeviceCount on
+    ROCm, which initialises HSA / KFD in the caller and keeps the handle open): the KFD topology's nodes with SIMDs, cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one of them is set."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """--gpus N > 1 (or --dry-launch) without torchrun's environment: start the N ranks as children of THIS process,
     which has not touched the GPU, relay their output (rank 0 prints the JSON line) and return the launcher's code."""
@@ -214,8 +238,7 @@ def self_launch(args):
         sys.stderr.write("bench.py: --gpus must be >= 1\n")
         return 2
     if not args.dry_launch and not os.environ.get("YART_BENCH_ONE_DEVICE"):
-        import torch
-        have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        have = visible_gpu_count()                # (sysfs: the launcher never opens the GPU)
         if have < n:
             sys.stderr.write(f"bench.py: --gpus {n} but only {have} HIP device(s) are visible: refusing to measure fewer GPUs than asked\n")
             return 2

@@ -307,6 +307,11 @@ int yart_hip_multi_render_tiles(YartMulti* multi, const YartCameraDesc* cam, con
  * per-sample radiance (before exposure) of n (x, y, sample) triples -> 3 floats each */
 int yart_hip_probe_samples(YartScene* scene, const YartCameraDesc* cam, const YartRenderParams* params,
                            uint32_t n, const uint32_t* xys, float* out_rgb, uint64_t* out_rays);
+/* Diagnostic: the ZSobol / FastOwen sampler alone on the device (reference core/sampler.hpp:84-173, scrambler.hpp:57-65): for each
+ * of n cases (pixel x, pixel y, sample index: 3 words) startPixelSample, then n_draws draws following `pattern` (1 = get1D, 2 = get2D);
+ * out receives sum(pattern) floats per case. use_tables != 0: through the per-render sampler tables the wavefront kernels read. */
+int yart_hip_probe_sampler(YartScene* scene, uint32_t spp, uint32_t tile, uint32_t n, const uint32_t* cases, uint32_t n_draws,
+                           const uint8_t* pattern, int use_tables, float* out);
 /* closest hit of n world rays (ox,oy,oz,dx,dy,dz) -> 16 floats each:
  * hit, t, u, v, px,py,pz, nx,ny,nz, tx,ty,tz, triIdx, lightIdx, backSide */
 int yart_hip_probe_hits(YartScene* scene, uint32_t n, const float* rays, float* out);

@@ -72,8 +72,9 @@ def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     differs from --gpus is refused as well."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    import torch
-    if torch.cuda.device_count() < 2:
+    sys.path.insert(0, ROOT)
+    import bench
+    if bench.visible_gpu_count() < 2:             # (counted from sysfs: this process does not open the GPU)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 2 and "refusing" in r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,

@@ -60,7 +60,7 @@ def test_bench_scene_vs_reference_every_pipeline(api, tmp_path):
     for name, flags in PIPELINE_FLAGS.items():
         img, st = scene.render(p, flags=flags)
         same, e = _compare(img, ref, f"sponza_class 240x136x16 / {name} vs {os.path.basename(exe)}")
-        assert abs(int(st["rays"]) - int(info["rays"])) <= max(4, 1e-4 * info["rays"]), name
+        assert int(st["rays"]) == int(info["rays"]), name      # ray counts are integers and the frames are bit-identical: exact
     scene.close()
 
 
@@ -297,11 +297,9 @@ def test_rccl_calls_of_the_merge_run_on_this_box(api):
 # everything around the transport runs there through the one-device rehearsals above).
 # ---------------------------------------------------------------------------------------------------------------
 def _n_devices():
-    try:
-        from yart_amd import api as _api
-        return int(_api.lib().yart_hip_device_count())
-    except Exception:
-        return 0
+    # (from the KFD topology in sysfs: evaluated at collection time, also by CPU-only runs — no HIP runtime call here)
+    import bench
+    return bench.visible_gpu_count()
 
 
 @pytest.mark.skipif(_n_devices() < 2, reason="needs >= 2 HIP devices (RCCL branch of multi_device.inc)")

@@ -1,12 +1,11 @@
 """GPU parity tests proper: everything goes through the C ABI (libyart_hip.so) on a real
 MI355X and is compared with the reference's outputs.
 
-Bars: integer / index results exact (BVH arrays, hit triangle ids, ray counts within the
-rare-flip budget); floating-point framebuffers within north_star's tolerance, RMSE < 1e-3
-in linear HDR against the reference framebuffer at identical sampler state. The device
-evaluates glibc's own sinf / cosf / logf / expf algorithms (csrc/ymath.hpp), so on this pool
-every frame is the reference's bit for bit; the tests print the identical-pixel fraction and
-assert the north_star bar, plus bit-equality where a drift would point at a real defect."""
+Bar: bit-exact. Integer / index results (BVH arrays, hit triangle ids, ray counts) are exact, and so is every
+floating-point framebuffer: the device evaluates the reference's operations in the reference's order, including
+glibc's own sinf / cosf / logf / expf algorithms (csrc/ymath.hpp), so every frame is the reference's bit for bit
+(conftest.bit_identical_or_drift; north_star's RMSE < 1e-3 is the fallback bar only under YART_ALLOW_LIBM_DRIFT=1,
+for a box whose glibc selects other libm variants)."""
 import os
 import subprocess
 
@@ -98,8 +97,11 @@ def test_per_sample_radiance_vs_reference(api, case):
     print(f"{case}: samples bit-identical {exact:.3f}, within 1e-4 {close:.3f}, rays {rays} vs {kat['probe_rays'][0]}")
     # with glibc's libm algorithms on the device every sample is the reference's bit for bit on this pool; should a box select
     # other libm variants the frames drift to the 1e-8 regime and this is the first test to say so
-    assert exact > 0.99 and close > 0.999, "probe samples differ from the reference's"
-    assert abs(rays - kat["probe_rays"][0]) <= max(4, 0.01 * kat["probe_rays"][0])
+    if os.environ.get("YART_ALLOW_LIBM_DRIFT"):
+        assert exact > 0.99 and close > 0.999, "probe samples differ from the reference's"
+    else:
+        assert exact == 1.0, "probe samples differ from the reference's"
+    assert rays == kat["probe_rays"][0]                     # an integer result: exact
     scene.close()
 
 
@@ -422,7 +424,7 @@ def test_wave_callback_and_abort(api):
                                     dict(wave=1, wave_samples=8, samples_taken=16, total_samples=16)]
     plain, _ = scene.render(p)
     assert np.array_equal(img.view(np.uint32), plain.view(np.uint32))
-    assert rmse(img, ref) < RMSE_TOL and np.mean(np.all(img.view(np.uint32) == ref.view(np.uint32), axis=-1)) > 0.5
+    bit_identical_or_drift(img, ref, "cornell_waves / render_waves")
     # the frame handed to the first callback is the render of the first wave alone
     first, _ = scene.render(dict(p, stop_sample=8))
     assert np.array_equal(seen[0][1].view(np.uint32), first.view(np.uint32))
@@ -460,8 +462,7 @@ def test_python_tile_renderer_mirror(api):
     r.on_render_complete = done.append
     r.render(); r.wait()
     assert waves == [(8, 8), (16, 8)] and len(done) == 1 and done[0].samples_taken == 16
-    assert rmse(done[0].buffer, ref) < RMSE_TOL
-    assert np.mean(np.all(done[0].buffer.view(np.uint32) == ref.view(np.uint32), axis=-1)) > 0.5
+    bit_identical_or_drift(done[0].buffer, ref, "cornell_waves / HipTileRenderer")
     # abort from the wave callback's thread: the aborted callback fires with the first wave's frame
     aborted = []
     r.on_render_complete, r.on_render_aborted = None, aborted.append
@@ -476,3 +477,56 @@ def test_python_tile_renderer_mirror(api):
     same = (mapped.buffer.view(np.uint32) == want.view(np.uint32)) | (np.isnan(mapped.buffer) & np.isnan(want))
     assert same.all()
     r.scene.close()
+
+
+# oracle/kat_common.hpp:45-54 (the cases and the draw pattern of the KAT files' "sampler" section): (spp, tile, px, py, sample)
+SAMPLER_CASES = [(16, 64, 3, 5, 7), (16, 64, 0, 0, 0), (16, 64, 255, 255, 15), (64, 64, 100, 37, 63), (256, 64, 1000, 700, 200),
+                 (256, 64, 1919, 1079, 255), (1024, 64, 640, 360, 1023), (512, 64, 3839, 2159, 300), (8, 64, 17, 9, 5),
+                 (32, 64, 77, 200, 31), (48, 64, 5, 6, 40), (16, 32, 40, 41, 3)]
+SAMPLER_PATTERN = [2, 2, 2, 1, 1, 1, 2, 1, 2, 1, 1, 1, 2, 1, 1, 2]
+
+
+@pytest.mark.parametrize("use_tables", [False, True])
+def test_device_sampler_vs_reference_kat(api, use_tables):
+    """The ZSobol / FastOwen sampler ON THE DEVICE (yart_hip_probe_sampler) against the compiled reference's draws (the "sampler"
+    section of the committed KAT files: 12 (spp, pixel, sample) cases x 16 draws) and SURVEY §8(c)'s known answers, bit for bit —
+    evaluated directly and through the per-render sampler tables the wavefront kernels read."""
+    kat = katlib.as_float(katlib.load(os.path.join(GOLDEN, "cornell.kat.json"))["sampler"]).reshape(len(SAMPLER_CASES), -1)
+    scene = api.DeviceScene(os.path.join(GOLDEN, "cornell.yscn"), device=0)
+    for i, (spp, tile, px, py, smp) in enumerate(SAMPLER_CASES):
+        got = scene.probe_sampler(spp, tile, [(px, py, smp)], SAMPLER_PATTERN, use_tables=use_tables)[0]
+        assert np.array_equal(got.view(np.uint32), kat[i].view(np.uint32)), (SAMPLER_CASES[i], use_tables)
+    # SURVEY.md §8(c): Sobol<FastOwen>(spp 16, res 64) pixel (3,5) sample 7; (spp 256) pixel (1000,700) sample 200
+    a = scene.probe_sampler(16, 64, [(3, 5, 7)], [2, 1, 2], use_tables=use_tables)[0]
+    assert np.array_equal(a, np.array([0.247990549, 0.85945183, 0.90101862, 0.263805777, 0.763566017], np.float32))
+    b = scene.probe_sampler(256, 64, [(1000, 700, 200)], [2, 1], use_tables=use_tables)[0]
+    assert np.array_equal(b, np.array([0.846162081, 0.899968386, 0.709087431], np.float32))
+    # several cases in one call (the tables then hold one pixel column per case)
+    same_spp = [c for c in SAMPLER_CASES if c[0] == 16 and c[1] == 64]
+    many = scene.probe_sampler(16, 64, [c[2:] for c in same_spp], SAMPLER_PATTERN, use_tables=use_tables)
+    for row, c in zip(many, same_spp):
+        assert np.array_equal(row.view(np.uint32), kat[SAMPLER_CASES.index(c)].view(np.uint32))
+    scene.close()
+
+
+def test_texture_footprint_budget_fallback(api, monkeypatch):
+    """The 2x2 footprint records of the textures are an optimisation with a memory budget (a third of the free device memory, or
+    YART_TEX_QUADS_MAX_MB): a scene whose records do not fit keeps its plain texel arrays only and renders the same frame."""
+    base = os.path.join(GOLDEN, "material")
+    p = load_params(base + ".txt")
+    ref = np.fromfile(base + ".f32", np.float32).reshape(p["size"][1], p["size"][0], 4)
+    monkeypatch.setenv("YART_TEX_QUADS_MAX_MB", "0")
+    scene = api.DeviceScene(base + ".yscn", device=0)
+    img, _ = scene.render(p)
+    bit_identical_or_drift(img, ref, "material / no footprint records")
+    scene.close()
+    from yart_amd import scenes
+    s, q = scenes.sponza_class(160, 90, 4, 6, tex=128, sky=128)     # bundled base / normal / metal-rough maps, a float sky
+    plain = api.DeviceScene(s, device=0)
+    a, _ = plain.render(q)
+    plain.close()
+    monkeypatch.delenv("YART_TEX_QUADS_MAX_MB")
+    full = api.DeviceScene(s, device=0)
+    b, _ = full.render(q)
+    full.close()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

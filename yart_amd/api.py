@@ -189,7 +189,7 @@ EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error
            "yart_hip_scene_create", "yart_hip_scene_load", "yart_hip_scene_destroy",
            "yart_hip_scene_load_gltf", "yart_hip_gltf_to_yscn",
            "yart_hip_render", "yart_hip_render_waves", "yart_hip_render_tiles", "yart_hip_render_device", "yart_hip_probe_samples",
-           "yart_hip_probe_hits", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_scene_create_flags", "yart_hip_bvh_build_device", "yart_hip_bvh_build_host", "yart_hip_debug_counters", "yart_hip_debug_shade_regions",
+           "yart_hip_probe_hits", "yart_hip_probe_sampler", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_scene_create_flags", "yart_hip_bvh_build_device", "yart_hip_bvh_build_host", "yart_hip_debug_counters", "yart_hip_debug_shade_regions",
            "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host",
            "yart_hip_multi_create", "yart_hip_multi_load", "yart_hip_multi_destroy", "yart_hip_multi_device_count",
            "yart_hip_multi_render", "yart_hip_multi_render_tiles", "yart_hip_multi_rccl_selftest"]
@@ -229,6 +229,7 @@ def lib(instrumented: bool = False):
         L.yart_hip_probe_samples.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParams),
                                              C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
         L.yart_hip_probe_hits.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.yart_hip_probe_sampler.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         L.yart_hip_tonemap_agx.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.yart_hip_encode_rgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.yart_hip_tonemap_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
@@ -473,6 +474,16 @@ class DeviceScene:
         out = np.empty((len(a), 16), np.float32)
         _check(self._L.yart_hip_probe_hits(self._h, len(a), a.ctypes.data_as(C.c_void_p),
                                          out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def probe_sampler(self, spp, tile, cases, pattern, use_tables=False):
+        """Device-side sampler draws (diagnostic): cases = [(px, py, sample)], pattern = sequence of 1 (get1D) / 2 (get2D);
+        returns float32 [n_cases, sum(pattern)]."""
+        cs = np.ascontiguousarray(np.asarray(cases, np.uint32).reshape(-1, 3))
+        pat = np.ascontiguousarray(np.asarray(pattern, np.uint8))
+        out = np.empty((len(cs), int(pat.sum())), np.float32)
+        _check(self._L.yart_hip_probe_sampler(self._h, int(spp), int(tile), len(cs), cs.ctypes.data_as(C.c_void_p), len(pat),
+                                              pat.ctypes.data_as(C.c_void_p), 1 if use_tables else 0, out.ctypes.data_as(C.c_void_p)), self._L)
         return out
 
     def debug_counters(self):

@@ -190,12 +190,7 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
       im.texU8.insert(im.texU8.end(), p, p + n);
       while (im.texU8.size() % 4) im.texU8.push_back(0);
     }
-    {
-      const size_t units = (size_t(t.width) * t.height * texQuadRecordBytes(t.channels, td.isFloat) + 15u) / 16u;
-      require(im.texQuadUnits + units < (size_t(1) << 32), "textures: more than 64 GB of footprint records");
-      td.quadOffset = uint32_t(im.texQuadUnits);
-      im.texQuadUnits += units;
-    }
+    td.quadOffset = kNoTexQuads;                               // its own footprint records: allocated below if something samples it directly
     im.textures.push_back(td);
   }
   auto texOk = [&](int32_t t, uint32_t ch, bool isFloat) {
@@ -269,6 +264,25 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
         *slot[k] = int32_t(im.textures.size());
         im.textures.push_back(c);
       }
+    }
+  }
+
+  // Own footprint records only for the textures something still samples directly: a material slot that was not bundled above, an
+  // emission / transmission / clearcoat map, an image light's map. (A texture reached only through bundle clones needs none: its
+  // records would be built and never read — 4x its texels.)
+  {
+    const uint32_t nTex = uint32_t(d.n_textures);
+    std::vector<uint8_t> direct(nTex, 0);
+    auto mark = [&](int32_t t) { if (t >= 0 && uint32_t(t) < nTex) direct[t] = 1; };
+    for (const MaterialDev& md : im.materials) { mark(md.texBase); mark(md.texNormal); mark(md.texMR); mark(md.texTransmission); mark(md.texClearcoat); mark(md.texEmission); }
+    for (uint32_t i = 0; i < d.n_lights; i++) mark(d.lights[i].texture);
+    for (uint32_t t = 0; t < nTex; t++) {
+      if (!direct[t]) continue;
+      TexDev& td = im.textures[t];
+      const size_t units = (size_t(td.width) * td.height * texQuadRecordBytes(td.channels, td.isFloat) + 15u) / 16u;
+      require(im.texQuadUnits + units < (size_t(1) << 32) - 1u, "textures: more than 64 GB of footprint records");
+      td.quadOffset = uint32_t(im.texQuadUnits);
+      im.texQuadUnits += units;
     }
   }
 

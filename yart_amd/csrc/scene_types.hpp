@@ -43,6 +43,7 @@ struct TexDev {            // core/texture.hpp:21-49
   // that the three lookups of a shaded hit — same uv, same position — touch one line and one page instead of three.
   uint32_t quadStride;
 };
+constexpr uint32_t kNoTexQuads = 0xffffffffu;   // TexDev::quadOffset of a texture without footprint records of its own (only sampled through bundle clones)
 YART_HD uint32_t texQuadRecordBytes(uint32_t channels, uint32_t isFloat) {
   if (isFloat) return channels == 1 ? 16u : channels == 2 ? 32u : 64u;
   return channels == 1 ? 4u : channels == 2 ? 8u : 16u;

@@ -255,6 +255,22 @@ __global__ void __launch_bounds__(kBlock) k_probe_samples(ProbeSampleArgs a) {
   atomicAdd(a.rays, (unsigned long long) rays);
 }
 
+// the sampler alone (diagnostic): per case startPixelSample + a pattern of draws (1 = get1D, 2 = get2D); with `tab` set the
+// draws go through the per-render sampler tables exactly as the wavefront kernels' do
+struct ProbeSamplerArgs { SamplerConfig cfg; const uint32_t* sobol; const uint32_t* cases; uint32_t n, nDraws, nOut, pad; const uint8_t* pattern; float* out; };
+__global__ void __launch_bounds__(kBlock) k_probe_sampler(ProbeSamplerArgs a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  Sampler s;
+  startPixelSample(s, a.cfg, a.cases[3 * i], a.cases[3 * i + 1], a.cases[3 * i + 2]);
+  s.pix = i;                                                 // (sampler tables: one pixel column per case)
+  float* o = a.out + size_t(i) * a.nOut;
+  for (uint32_t k = 0; k < a.nDraws; k++) {
+    if (a.pattern[k] == 2) { const f2 v = get2D(s, a.cfg, a.sobol); *o++ = v.x; *o++ = v.y; }
+    else *o++ = get1D(s, a.cfg);
+  }
+}
+
 struct ProbeHitArgs { SceneDev sc; const float* rays; uint32_t n; float* out; uint64_t* spill; };
 __global__ void __launch_bounds__(kBlock) k_probe_hits(ProbeHitArgs a) {
   __shared__ uint64_t ldsStack[kLdsStack * kBlock];
@@ -333,6 +349,7 @@ struct YartScene {
   HostImage host;
   SceneDev dev{};
   int numCUs = 256;
+  bool texQuadsOn = true;      // the textures' 2x2 footprint records are on the device (uploadScene: they fit the budget)
   // device copies of the scene image
   DevBuf<f4> resumeRec; DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<Wide8Node> wideNodes; DevBuf<LeafTri> wideTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
@@ -378,10 +395,21 @@ void uploadScene(YartScene& s) {
     while (cls.size() % 4u) cls.push_back(0);          // (the shade kernel copies the classes into LDS a word at a time)
     s.matClass.upload(cls);
   }
-  // the textures' 2x2 footprint records: expanded here from the plain texel arrays just uploaded
-  s.texQuads.ensure(std::max<size_t>(h.texQuadUnits, 1) * 16u);
+  // The textures' 2x2 footprint records: expanded here from the plain texel arrays just uploaded — unless they do not fit a
+  // budget: more than a third of the free device memory (or YART_TEX_QUADS_MAX_MB megabytes) and the kernels take their bilinear
+  // taps from the plain texel arrays (bsdf.hpp::texQuad: sc.texQuads == nullptr; same taps, same arithmetic, same frame).
+  bool quads = true;
+  {
+    size_t freeB = 0, totalB = 0;
+    HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+    size_t budget = freeB / 3;
+    if (const char* e = std::getenv("YART_TEX_QUADS_MAX_MB")) budget = size_t(std::max<long long>(0, std::atoll(e))) << 20;
+    if (h.texQuadUnits * 16u > budget) quads = false;
+  }
+  s.texQuadsOn = quads;
+  s.texQuads.ensure(quads ? std::max<size_t>(h.texQuadUnits, 1) * 16u : 16u);
   for (const TexDev& t : h.textures) {
-    if (t.width == 0u) continue;
+    if (!quads || t.width == 0u || t.quadOffset == kNoTexQuads) continue;
     TexQuadArgs qa{s.texU8.p, s.texF32.p, t, s.texQuads.p + size_t(t.quadOffset) * 16u};
     const size_t n = size_t(t.width) * t.height;
     hipLaunchKernelGGL(k_tex_quads, dim3(uint32_t(std::min<size_t>((n + kBlock - 1) / kBlock, 65535u))), dim3(kBlock), 0, nullptr, qa);
@@ -394,7 +422,7 @@ void uploadScene(YartScene& s) {
   d.wideNodes = reinterpret_cast<const uint8_t*>(s.wideNodes.p); d.wideTris = s.wideTris.p;
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
-  d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.texQuads = s.texQuads.p; d.lights = s.lights.p; d.envs = s.envs.p;
+  d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.texQuads = s.texQuadsOn ? s.texQuads.p : nullptr; d.lights = s.lights.p; d.envs = s.envs.p;
   d.envData = s.envData.p; d.envGuide = s.envGuide.p; d.nodeWorld = s.nodeWorld.p; d.tlas = s.tlas.p; d.nTlas = h.tlas.size() > 1 || (h.tlas.size() == 1 && h.tlas[0].b) ? uint32_t(h.tlas.size()) : 0u; d.infiniteLights = s.infiniteLights.p; d.areaLights = s.areaLights.p;
   d.areaPowerCdf = s.areaPowerCdf.p; d.lut = s.lut.p;
   s.dev = d;
@@ -1217,6 +1245,46 @@ int yart_hip_probe_hits(YartScene* scene, uint32_t n, const float* rays, float* 
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(out, res.p, size_t(n) * 16 * 4, hipMemcpyDeviceToHost));
+  });
+}
+
+int yart_hip_probe_sampler(YartScene* scene, uint32_t spp, uint32_t tile, uint32_t n, const uint32_t* cases, uint32_t n_draws,
+                           const uint8_t* pattern, int use_tables, float* out) {
+  return guarded([&] {
+    require(scene && cases && pattern && out && n > 0 && n_draws > 0 && n_draws <= 64 && spp > 0 && tile > 0, "probe_sampler: bad argument");
+    YartScene& s = *scene;
+    std::lock_guard<std::mutex> lk(s.mu);
+    HIP_CHECK(hipSetDevice(s.device));
+    uint32_t nOut = 0;
+    for (uint32_t k = 0; k < n_draws; k++) { require(pattern[k] == 1 || pattern[k] == 2, "probe_sampler: pattern entries are 1 or 2"); nOut += pattern[k]; }
+    for (uint32_t i = 0; i < n; i++) require(cases[3 * i] < 65536u && cases[3 * i + 1] < 65536u && cases[3 * i + 2] < spp, "probe_sampler: pixel / sample out of range");
+    DevBuf<uint32_t> dCases; DevBuf<uint8_t> dPat; DevBuf<float> dOut;
+    dCases.upload(std::vector<uint32_t>(cases, cases + size_t(n) * 3)); dPat.upload(std::vector<uint8_t>(pattern, pattern + n_draws));
+    dOut.ensure(size_t(n) * nOut);
+    ProbeSamplerArgs a{};
+    a.cfg = makeSamplerConfig(spp, tile);
+    a.sobol = reinterpret_cast<const uint32_t*>(s.dev.lut + LutDev::sobol);
+    a.cases = dCases.p; a.n = n; a.nDraws = n_draws; a.nOut = nOut; a.pattern = dPat.p; a.out = dOut.p;
+    DevBuf<uint32_t> dPix; DevBuf<uint64_t> entries, hash; DevBuf<uint32_t> sobol1;
+    if (use_tables) {
+      // the tables of a render whose pixel list is the cases' pixels (k_sampler_tables, as renderToDevice builds them)
+      require(uint64_t(spp) <= (1ull << a.cfg.log2spp), "probe_sampler: the sampler tables need spp <= 2^log2spp");
+      std::vector<uint32_t> pix(n);
+      for (uint32_t i = 0; i < n; i++) pix[i] = cases[3 * i] | (cases[3 * i + 1] << 16);
+      dPix.upload(pix);
+      const uint32_t dims = 256u;
+      entries.ensure(size_t(dims) * n); hash.ensure(dims + 3); sobol1.ensure(8 * 256);
+      SamplerTabArgs ta{};
+      ta.cfg = a.cfg; ta.pixels = dPix.p; ta.nPixels = n; ta.dims = dims; ta.entries = entries.p; ta.hash = hash.p; ta.sobol1 = sobol1.p;
+      ta.matrix52 = a.sobol;
+      hipLaunchKernelGGL(k_sampler_tables, dim3(64), dim3(kBlock), 0, nullptr, ta);
+      HIP_CHECK(hipGetLastError());
+      a.cfg.tab.entries = entries.p; a.cfg.tab.hash = hash.p; a.cfg.tab.sobol1 = sobol1.p; a.cfg.tab.dims = dims; a.cfg.tab.stride = n;
+    }
+    hipLaunchKernelGGL(k_probe_sampler, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, a);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, dOut.p, size_t(n) * nOut * 4, hipMemcpyDeviceToHost));
   });
 }
 

@@ -129,12 +129,18 @@ typedef struct YartRenderParams {
    * reference's unit of parallel work. Which process renders a pixel does not change it (the sampler only
    * knows tile_size), so a smaller block only evens out the load between GPUs. */
   uint32_t shard_tile;
-  /* Upper bound on the (pixel, sample) paths in flight per batch; 0 = as many as the free device memory holds
-   * (the whole 1080p x 256 spp frame on a 288 GB MI355X). A wave is rendered batch by batch over this rank's
-   * pixels in tile order, every batch through all bounces and the estimator, so a smaller batch means finished
-   * tiles arrive earlier (yart_hip_render_tiles) and less memory is held, at the price of more launches. The
-   * frame does not depend on it. */
+  /* Upper bound on the (pixel, sample) paths per batch; 0 = 2^28 (a fixed number: the memory a render holds does not depend on
+   * what happens to be free on the device; only a device that cannot hold the batch renders smaller ones). A wave is rendered
+   * batch by batch over this rank's pixels in tile order, every batch through all bounces and the estimator: 287 bytes per path
+   * of the batch (path state, queues, per-sample radiance, the compacted states of the late bounces). A smaller batch means
+   * finished tiles arrive earlier (yart_hip_render_tiles) and less memory is held, at ~10 ms per batch on an MI355X (the C3 frame
+   * of 531 M paths: +1.4 % in 2 batches, +4.5 % in 4, +19 % in 16). The frame does not depend on it. */
   uint32_t max_batch_paths;
+  /* ABI 3. With YART_FLAG_PATH_POOL: the path slots of the pool (0 = 2^25: 5.6 GB). The paths of a batch are started in these
+   * slots, and whenever a path ends its slot takes the batch's next (pixel, sample) — path regeneration, as a worker of the
+   * reference takes the next tile the moment it has finished one (tile-renderer.hpp:161-167) — so the path state is bounded
+   * by the pool (168 bytes per slot) and only 16 bytes per path of the batch remain. The frame does not depend on it. */
+  uint32_t pool_paths;
 } YartRenderParams;
 #define YART_ESTIMATOR_GMON 0u      /* core/estimator.hpp:148-198 */
 #define YART_ESTIMATOR_MEAN 1u      /* :29-46 */
@@ -156,9 +162,11 @@ typedef struct YartRenderParams {
 #define YART_FLAG_WIDE_TREES 256u   /* ABI 3: the lean traversal kernels walk their own 8-wide trees (csrc/bvh8_build.hpp) instead of the
                                        reference's binary tree in the reference's order (the default); rays whose result could depend on
                                        that order are handed to the general kernels. Same frame either way */
-/* ABI history. 3: YART_FLAG_WIDE_TREES; YartStats grew (wide_* fields at the end); value 128 has meant NO_RESUME since the end of
+#define YART_FLAG_PATH_POOL 512u    /* ABI 3: run a batch through a pool of pool_paths path slots with path regeneration (a slot whose path has ended
+                                       takes the batch's next path) instead of one slot per path of the batch. Same frame either way */
+/* ABI history. 3: YART_FLAG_WIDE_TREES, YART_FLAG_PATH_POOL; YartStats grew (wide_* fields at the end); value 128 has meant NO_RESUME since the end of
  * ABI 2 (it selected a since-removed 4-wide re-layout before: an old client passing it gets the same frame, a little slower);
- * value 1024 is retired and ignored; YartTileInfo.rays is a real count; yart_hip_multi_render_tiles was added. */
+ * YartRenderParams grew (pool_paths); max_batch_paths = 0 now means a fixed 2^28 paths, no longer a share of the free device memory; value 1024 is retired and ignored; YartTileInfo.rays is a real count; yart_hip_multi_render_tiles was added. */
 
 /* Renderer::RenderData counters (src/core/renderer.hpp:22-28) + per-stage device time. */
 typedef struct YartStats {

@@ -369,3 +369,24 @@ def test_two_process_render_sharded_nccl(api):
         pr.join(timeout=120)
         assert pr.exitcode == 0
     assert res[0] and res[1]
+
+
+def test_path_pool_sizes(api):
+    """YART_FLAG_PATH_POOL: the batch runs through a pool of path slots, a slot whose path has ended takes the batch's next
+    (pixel, sample). Pools far smaller than the batch (many rounds of refill, the drain at the end of every batch), a pool of
+    one wave, a pool larger than the batch, several batches per wave, two progressive waves: always the default pipeline's
+    frame and ray count, bit for bit."""
+    from yart_amd import scenes
+    s, p = scenes.sponza_class(160, 90, 8, 8, tex=64, sky=64)
+    scene = api.DeviceScene(s, device=0)
+    ref, st0 = scene.render(p)
+    for q in (dict(pool_paths=4096), dict(pool_paths=64), dict(pool_paths=1 << 22), dict(pool_paths=5000, max_batch_paths=30000),
+              dict(pool_paths=3000, first_wave=2, max_wave=4)):
+        base = ref
+        if "first_wave" in q:
+            base, _ = scene.render(dict(p, first_wave=2, max_wave=4))
+        img, st = scene.render(dict(p, **q), flags=512)
+        assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), q
+        assert int(st["rays"]) == int(st0["rays"]), q
+        assert st["pipeline_flags"] & 512
+    scene.close()

@@ -40,6 +40,8 @@ PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+shade_sort": 2, "w
                   # the lean kernels walk their own 8-wide trees (quantised child boxes, octant order) instead of the reference's
                   # binary tree in its order; rays that could depend on that order go to the general kernels
                   "wavefront+wide_trees": 256,
+                  # a pool of path slots with path regeneration instead of one slot per path of the batch
+                  "wavefront+path_pool": 512,
                   # scenes of 64 nodes and more take their candidate windows from the top-level hierarchy by default; the two
                   # forms without it: chunked candidate masks / per-lane walk of the node list by size (262144), the walk (65536)
                   "wavefront+node_masks": 262144, "wavefront+node_walk": 65536}

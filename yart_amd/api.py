@@ -41,6 +41,7 @@ FLAG_NO_COMPACTION = 32
 FLAG_NO_SHADE_SORT = 64
 FLAG_NO_RESUME = 128
 FLAG_WIDE_TREES = 256
+FLAG_PATH_POOL = 512
 
 
 class YartError(RuntimeError):
@@ -104,7 +105,8 @@ class RenderParams(C.Structure):
                 ("max_wave_samples", C.c_uint32), ("tile_size", C.c_uint32), ("max_depth", C.c_uint32),
                 ("background", C.c_float * 3), ("rank", C.c_uint32), ("world_size", C.c_uint32),
                 ("flags", C.c_uint32), ("start_sample", C.c_uint32), ("stop_sample", C.c_uint32),
-                ("estimator", C.c_uint32), ("shard_tile", C.c_uint32), ("max_batch_paths", C.c_uint32)]
+                ("estimator", C.c_uint32), ("shard_tile", C.c_uint32), ("max_batch_paths", C.c_uint32),
+                ("pool_paths", C.c_uint32)]
 
 
 def _plain(v):
@@ -302,6 +304,7 @@ def make_params(p: dict, rank=0, world_size=1, flags=0) -> RenderParams:
     r.estimator = int(p.get("estimator", ESTIMATOR_GMON))
     r.shard_tile = int(p.get("shard_tile", 0))
     r.max_batch_paths = int(p.get("max_batch_paths", 0))
+    r.pool_paths = int(p.get("pool_paths", 0))
     return r
 
 

@@ -54,6 +54,25 @@ __device__ __forceinline__ uint32_t leanChunk(uint32_t count, uint32_t nWaves) {
   return c < 64u ? 64u : (c > YART_LEAN_CHUNK_MAX ? YART_LEAN_CHUNK_MAX : c);
 }
 
+// One top-up of a wave's private range of the queue. The size shrinks as the queue runs out (guided self-scheduling): a launch ends
+// when its LAST wave has finished its last range, and with ranges of 256 entries to the end that wave works ~1 ms after the others
+// have run dry — per launch, i.e. ~16 times per batch (profiles/r4_batch_sweep.txt: ~10 ms per batch of any size). How much is left
+// is estimated from the end of the wave's own previous range (`lastEnd`; the waves advance together: the true cursor is at most
+// nWaves * chunk further) — NOT read from the cursor: that word already takes one atomic per top-up from every wave, and a second
+// access per top-up doubled the traversal kernels' time (measured).
+__device__ __forceinline__ uint32_t leanTopUp(uint32_t* cursor, uint32_t count, uint32_t nWaves, uint32_t chunk, uint32_t lastEnd, bool isLeader, int leader, uint32_t& size) {
+  uint32_t sz = chunk;
+  if (chunk > 64u) {                                            // (wave-uniform)
+    const uint32_t remaining = count > lastEnd ? count - lastEnd : 0u;
+    const uint32_t g = ((remaining / (nWaves * 4u)) + 63u) & ~63u;
+    sz = g < 64u ? 64u : (g > chunk ? chunk : g);
+  }
+  uint32_t c = 0;
+  if (isLeader) c = atomicAdd(cursor, sz);
+  size = sz;
+  return uint32_t(__shfl(int(c), leader));
+}
+
 struct LeanRay { f3 o, d; float tMax; Sampler smp; };        // smp: general variant only (alpha tests)
 
 // Fetch(slot) -> LeanRay (world ray of the path in that slot; deterministic, may be called again)
@@ -175,20 +194,18 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
         if (nWaves * 64u >= count) exhausted = true;
       } else {
         const uint32_t rem = chunkEnd - chunkNext;
-        uint32_t fresh = 0;
+        uint32_t fresh = 0, got = chunk;
         if (rem < nIdle) {                                      // (wave-uniform)
           const int leader = __ffsll((long long) idle) - 1;
-          uint32_t c = 0;
-          if (int(lane) == leader) c = atomicAdd(cursor, chunk);
-          fresh = nWaves * 64u + __shfl(c, leader);
+          fresh = nWaves * 64u + leanTopUp(cursor, count, nWaves, chunk, chunkEnd, int(lane) == leader, leader, got);
         }
         k = rank < rem ? chunkNext + rank : fresh + (rank - rem);
-        if (rem < nIdle) { chunkNext = fresh + (nIdle - rem); chunkEnd = fresh + chunk; }
+        if (rem < nIdle) { chunkNext = fresh + (nIdle - rem); chunkEnd = fresh + got; }
         else chunkNext += nIdle;
         if (chunkNext >= count) exhausted = true;               // (ranges are handed out in increasing order: nothing is left behind it)
       }
       if (!has) {
-        if (k < count) {
+        if (k < count && queue[k] != kWfFreeSlot) {             // (path pool: the queue is the slots in order, free ones marked)
           WF_PHASE(tally, 6);                                   // refills / rays fetched
           const uint32_t word = queue[k];
           const bool hasRec = !kFast && (word & kResumeFlag) != 0u && (word & ~kResumeFlag) < stk.recCap;

@@ -90,20 +90,18 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
         if (nWaves * 64u >= count) exhausted = true;
       } else {
         const uint32_t rem = chunkEnd - chunkNext;
-        uint32_t fresh = 0;
+        uint32_t fresh = 0, got = chunk;
         if (rem < nIdle) {                                      // (wave-uniform)
           const int leader = __ffsll((long long) idle) - 1;
-          uint32_t c = 0;
-          if (int(lane) == leader) c = atomicAdd(cursor, chunk);
-          fresh = nWaves * 64u + __shfl(c, leader);
+          fresh = nWaves * 64u + leanTopUp(cursor, count, nWaves, chunk, chunkEnd, int(lane) == leader, leader, got);
         }
         k = rank < rem ? chunkNext + rank : fresh + (rank - rem);
-        if (rem < nIdle) { chunkNext = fresh + (nIdle - rem); chunkEnd = fresh + chunk; }
+        if (rem < nIdle) { chunkNext = fresh + (nIdle - rem); chunkEnd = fresh + got; }
         else chunkNext += nIdle;
         if (chunkNext >= count) exhausted = true;               // (ranges are handed out in increasing order: nothing is left behind it)
       }
       if (!has) {
-        if (k < count) {
+        if (k < count && queue[k] != kWfFreeSlot) {             // (path pool: the queue is the slots in order, free ones marked)
           WF_PHASE(tally, 6);                                   // refills / rays fetched
           slot = queue[k];
           const LeanRay r = fetch(slot);

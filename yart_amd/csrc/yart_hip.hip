@@ -49,6 +49,9 @@ constexpr int kBlock = 256;            // 4 waves per workgroup
 constexpr int kLdsStack = 24;          // traversal stack entries kept in LDS per lane (8 B each)
 constexpr int kSpillDepth = int(kRefStackDepth) - kLdsStack;
 constexpr int kSpillDepthMax = int(kRefStackDepth);   // spill area sized for the shallowest LDS stack
+constexpr uint64_t kDefaultBatchPaths = 1ull << 28;   // YartRenderParams::max_batch_paths = 0: 268 M paths (batch-synchronous: 77 GB; path pool: 4.3 GB of per-sample records)
+constexpr uint64_t kDefaultPoolPaths = 1ull << 25;    // YartRenderParams::pool_paths = 0: 33.5 M slots, 5.6 GB
+constexpr int kPoolLag = 4;                            // the host looks at the counters of the round before the previous one (ring of 4)
 constexpr int kNumCounters = 32;       // [0] rays, [1..4] instrumented tallies, [8..31] debug statistics
 
 thread_local std::string g_lastError;
@@ -366,6 +369,9 @@ struct YartScene {
   DevBuf<f4> wfTail[2][9];                 // compacted states of the late bounces (1/2 and 1/4 of the batch)
   DevBuf<uint32_t> wfTailMap[2];
   DevBuf<WfDyn> wfDyn;
+  DevBuf<uint32_t> poolMap;                // path pool: the path (index of L) each slot carries, kWfFreeSlot = free
+  uint32_t* poolHost = nullptr;            // pinned: the queue counters of the last rounds (the host's view of "is the batch done")
+  ~YartScene() { if (poolHost) (void)hipHostFree(poolHost); }
   DevBuf<uint32_t> qA, qB, qS, qR, wfCounters; // wavefront queues
   DevBuf<uint64_t> smpEntries, smpHash; DevBuf<uint32_t> smpSobol1;   // SamplerTables of the current render
   std::vector<uint32_t> pixelsHost;
@@ -663,32 +669,53 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     if (s.nodeBits.n < need) { s.nodeBits.ensure(need); HIP_CHECK(hipMemsetAsync(s.nodeBits.p, 0, need * 8, stream)); }
   }
 
-  // Batch = as many pixels (x all samples of a wave) as half of the device memory that is free — or
-  // already held by this scene's scratch buffers — allows, up to kWfMaxPaths: 172 B per path (144 B of
-  // state, four queue words, 12 B of per-sample radiance). On a 288 GB MI355X the whole 1080p x 256 spp
-  // frame (531 M paths, 91 GB) is one batch: every launch is as large as it can be and the latency-bound
-  // tails of the late bounces are paid once per render instead of once per batch.
+  // Batch = the pixels (x all samples of a wave) rendered together: max_batch_paths, by default kDefaultBatchPaths — a fixed
+  // number, no longer a share of the free device memory (round 3 sized ONE batch to 60 % of it: 150 GB for the C3 frame); only if
+  // that does not fit the device is it cut down to what does. The default pipeline is batch-synchronous: one slot per path of the
+  // batch (287 bytes with the compacted tail states), every bounce one launch per stage over the paths still alive. What a smaller
+  // batch costs (profiles/r4_ab_path_pool.txt): ~10 ms per batch of any size — the tail of every launch, when the GPU waits for
+  // the slowest rays of the last waves — so the C3 frame in 2 / 4 / 8 / 16 batches is 1.4 / 4.5 / 9.7 / 19 % slower than in one.
+  // YART_FLAG_PATH_POOL: the batch runs through a POOL of pool_paths slots with path regeneration instead (168 bytes per slot +
+  // 16 per path of the batch): bounded memory at any frame size, every launch pool-sized until the batch runs out — and ~25 %
+  // slower on the C3 frame, because a wave's lanes then hold paths of every generation (same file).
   const uint32_t maxWave = std::min(p.max_wave_samples, p.samples);
   const uint32_t waveCap = std::max(std::min(p.first_wave_samples, p.samples), maxWave);
-  size_t freeB = 0, totalB = 0;
-  HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
-  uint64_t held = uint64_t(s.L.n) * 16 + (uint64_t(s.qA.n) + s.qB.n + s.qS.n + s.qR.n) * 4 + uint64_t(s.resumeRec.n) * 16;
+  const bool pool = !mega && (p.flags & YART_FLAG_PATH_POOL) != 0;
   uint32_t resumeCap = 0;
-  for (auto& b : s.wf) held += uint64_t(b.n) * 16;
-  for (auto& t : s.wfTail) for (auto& b : t) held += uint64_t(b.n) * 16;
-  held += (uint64_t(s.wfTailMap[0].n) + s.wfTailMap[1].n) * 4;
-  held += uint64_t(s.smpEntries.n) * 8;      // the sampler tables of the previous render stay allocated
-  // with compaction: two tail states of 1/2 and 1/4 of the batch (9 x 16 B + a slot map word each) = 111 B per path
-  const bool compact = !mega && !(p.flags & YART_FLAG_NO_COMPACTION);
-  const uint64_t perPath = mega ? 16 : compact ? 287 : 176;
-  uint64_t maxPaths = std::max<uint64_t>((uint64_t(freeB) + held) * (compact ? 6 : 5) / 10 / perPath, 1u << 20);
-  if (!mega) maxPaths = std::min<uint64_t>(maxPaths, kWfMaxPaths);
+  const bool compact = !mega && !pool && !(p.flags & YART_FLAG_NO_COMPACTION);
+  uint64_t maxPaths = p.max_batch_paths ? p.max_batch_paths : kDefaultBatchPaths;
+  if (!pool && !mega) {
+    // (safety only: a device that cannot hold the batch renders smaller ones)
+    size_t freeB = 0, totalB = 0;
+    HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+    uint64_t held = uint64_t(s.L.n) * 16 + (uint64_t(s.qA.n) + s.qB.n + s.qS.n + s.qR.n) * 4 + uint64_t(s.resumeRec.n) * 16;
+    for (auto& b : s.wf) held += uint64_t(b.n) * 16;
+    for (auto& t : s.wfTail) for (auto& b : t) held += uint64_t(b.n) * 16;
+    held += (uint64_t(s.wfTailMap[0].n) + s.wfTailMap[1].n) * 4;
+    held += uint64_t(s.smpEntries.n) * 8;      // the sampler tables of the previous render stay allocated
+    // with compaction: two tail states of 1/2 and 1/4 of the batch (9 x 16 B + a slot map word each) = 111 B per path
+    const uint64_t perPath = compact ? 287 : 176;
+    const uint64_t fits = std::max<uint64_t>((uint64_t(freeB) + held) * 8 / 10 / perPath, 1u << 20);
+    maxPaths = std::min<uint64_t>(std::min<uint64_t>(maxPaths, fits), kWfMaxPaths);
+  }
   maxPaths = std::min<uint64_t>(maxPaths, (1ull << 31) - 64);
-  if (p.max_batch_paths) maxPaths = std::min<uint64_t>(maxPaths, p.max_batch_paths);
   uint32_t chunk = uint32_t(std::min<uint64_t>(nPix ? nPix : 1, std::max<uint64_t>(maxPaths / waveCap, 1)));
+  if (nPix > chunk) {                            // batches of equal size (the last one is not a sliver)
+    const uint32_t nb = (nPix + chunk - 1) / chunk;
+    chunk = (nPix + nb - 1) / nb;
+  }
   s.L.ensure(size_t(chunk) * waveCap);
+  uint32_t poolSlots = 0;
   if (!mega) {
-    const size_t np = size_t(chunk) * waveCap;
+    const size_t npBatch = size_t(chunk) * waveCap;
+    size_t np = npBatch;
+    if (pool) {
+      const size_t want = p.pool_paths ? p.pool_paths : kDefaultPoolPaths;
+      np = std::max<size_t>(64, (std::min(want, npBatch) + 63) & ~size_t(63));
+      poolSlots = uint32_t(np);
+      s.poolMap.ensure(np);
+      if (!s.poolHost) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.poolHost), kPoolLag * WC_COUNT * sizeof(uint32_t)));
+    }
     for (auto& b : s.wf) b.ensure(np);
     if (compact) {
       for (int t = 0; t < 2; t++) {
@@ -700,8 +727,8 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     }
     s.qA.ensure(np); s.qB.ensure(np); s.qS.ensure(np); s.qR.ensure(np); s.wfCounters.ensure(WC_COUNT);
     // resume records of the rays the lean kernels hand to the general ones (traverse.hpp: 192 B each): room for an eighth of
-    // the batch (C3 hands over 6-7 % of its rays; a ray that finds no record is restarted, as all of them were before). Taken
-    // from the share of the memory the batch leaves free. YART_RESUME_CAP: records (tests of the fallback), 0 = restarts only.
+    // the slots (C3 hands over 6-7 % of its rays; a ray that finds no record is restarted, as all of them were before).
+    // YART_RESUME_CAP: records (tests of the fallback), 0 = restarts only.
     if (!(p.flags & YART_FLAG_NO_RESUME)) {
       // (+ one range of 64 per wave of the largest grid: a wave takes its records 64 at a time and may leave a range unfinished)
       size_t cap = std::max<size_t>(np / 8, std::min<size_t>(np, 1u << 16)) + size_t(gridMax) * kBlock;
@@ -762,6 +789,88 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         hipLaunchKernelGGL(k_render_mega, dim3(gridMega), dim3(kBlock), 0, stream, a);
         HIP_CHECK(hipGetLastError());
         tMega.end(stream);
+      } else if (pool) {
+        WfArgs a{};
+        a.sc = s.dev; a.cam = cam; a.rc = rcw; a.pixBase = c0;
+        a.st.ray0 = s.wf[0].p; a.st.ray1 = s.wf[1].p; a.st.thr = s.wf[2].p; a.st.acc = s.wf[3].p;
+        a.st.hit0 = s.wf[4].p; a.st.hit1 = s.wf[5].p; a.st.sh0 = s.wf[6].p; a.st.sh1 = s.wf[7].p; a.st.sh2 = s.wf[8].p;
+        a.qA = s.qA.p; a.qB = s.qB.p; a.qS = s.qS.p; a.qR = s.qR.p; a.counters = s.wfCounters.p;
+        a.pixels = s.pixels.p + c0; a.nPaths = n * uint32_t(waveSamples); a.spp = uint32_t(waveSamples);
+        a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p; a.stats = s.counters.p; a.spill = s.spill.p;
+        a.matClass = s.matClass.p;
+        a.resumeRec = resumeCap ? s.resumeRec.p : nullptr; a.resumeCap = resumeCap;
+        a.sc.nodeBits = s.nodeBits.p; a.sc.nodeBitWords = nodeBitWords;
+        a.slotMap = s.poolMap.p;
+        a.poolSlots = uint32_t(std::min<uint64_t>(poolSlots, (uint64_t(a.nPaths) + 63u) & ~uint64_t(63)));
+        const uint32_t init[WC_COUNT] = {a.poolSlots, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_CHECK(hipMemcpyAsync(s.wfCounters.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_wf_pool_init, dim3(s.numCUs * 4), dim3(kBlock), 0, stream, s.poolMap.p, a.poolSlots);
+        HIP_CHECK(hipGetLastError());
+        // Rounds: every round starts new paths in the free slots and takes every live path one bounce further. The host does not
+        // know when the batch is done; it reads the counters of the round before the previous one (a copy into pinned memory and
+        // an event per round, never waited for) and stops launching when that round left no live path and nothing to start:
+        // two or three empty rounds at the end instead of a host synchronisation per round.
+        hipEvent_t evRound[kPoolLag];
+        for (int k = 0; k < kPoolLag; k++) HIP_CHECK(hipEventCreateWithFlags(&evRound[k], hipEventDisableTiming));
+        const uint64_t maxRounds = (uint64_t(a.nPaths) / a.poolSlots + 2u) * (rc.maxDepth + 1u) + 16u;   // (a path lives at most maxDepth rounds)
+        bool done = false;
+        for (uint64_t round = 0; !done; round++) {
+          if (round > maxRounds) throw HipError("path pool: the batch did not finish within its bound of rounds");
+          tShade.begin(stream);
+          hipLaunchKernelGGL(k_wf_refill, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
+          HIP_CHECK(hipGetLastError());
+          tShade.end(stream);
+          {   // the live slots of this round, for the host (WC_NEXT: k_wf_refill)
+            uint32_t* snap = s.poolHost + size_t(round % kPoolLag) * WC_COUNT;
+            HIP_CHECK(hipMemcpyAsync(snap, s.wfCounters.p, WC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipEventRecord(evRound[round % kPoolLag], stream));
+          }
+          tExtend.begin(stream);
+          if (general) {
+            hipLaunchKernelGGL(k_wf_extend<false>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+          } else {
+            tLean.begin(stream);
+            hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
+            tLean.end(stream);
+            if (refill) hipLaunchKernelGGL(kRetryE, dim3(gridRetryE), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(k_wf_reset_retry, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
+          }
+          HIP_CHECK(hipGetLastError());
+          tExtend.end(stream);
+          tShade.begin(stream);
+          tShadeK.begin(stream);
+          hipLaunchKernelGGL(kShade, dim3(gridShade), dim3(kShadeBlock), 0, stream, a);
+          HIP_CHECK(hipGetLastError());
+          tShadeK.end(stream);
+          tShade.end(stream);
+          tConnect.begin(stream);
+          if (general) {
+            hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
+          } else {
+            tShadowLean.begin(stream);
+            hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
+            tShadowLean.end(stream);
+            if (refill) hipLaunchKernelGGL(kRetryS, dim3(gridRetryS), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
+          }
+          HIP_CHECK(hipGetLastError());
+          tConnect.end(stream);
+          tShade.begin(stream);
+          hipLaunchKernelGGL(k_wf_roulette, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
+          HIP_CHECK(hipGetLastError());
+          tShade.end(stream);
+          hipLaunchKernelGGL(k_wf_pool_advance, dim3(1), dim3(64), 0, stream, s.wfCounters.p, a.poolSlots);
+          HIP_CHECK(hipGetLastError());
+          if (round >= 2) {
+            const uint64_t old = round - 2;
+            // (rounds far ahead of the device would only queue launches: wait for the round before the previous one)
+            HIP_CHECK(hipEventSynchronize(evRound[old % kPoolLag]));
+            const uint32_t* c = s.poolHost + size_t(old % kPoolLag) * WC_COUNT;
+            if (c[WC_NEXT] == 0u) done = true;                  // no live slot after its refill: nothing left to start either
+          }
+        }
+        for (int k = 0; k < kPoolLag; k++) (void)hipEventDestroy(evRound[k]);
       } else {
         WfArgs a{};
         a.sc = s.dev; a.cam = cam; a.rc = rcw; a.pixBase = c0;

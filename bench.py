@@ -27,7 +27,10 @@ with `per_rank` = every rank's device time and stage times and `reduce_ms` = the
                 bytes per launch / HIP-event launch time against the roof that binds (HBM for the shade kernel,
                 the L2 for the BVH walks whose working set is cache resident), and `traffic` = FETCH_SIZE x 2 +
                 WRITE_SIZE of that kernel measured by two rocprofv3 --pmc child runs of this workload started
-                BEFORE this process touches the GPU (null when they cannot run)
+                BEFORE this process touches the GPU (null when they cannot run); a third child run collects the SQ
+                counters of the same workload: per kernel `lane_util` (how full the issued vector instructions are),
+                `valu_busy` (share of the SIMD cycles that issue one) and, for the traversal kernels, `valu_frac` (the
+                box + triangle tests' lane-operations against the peak lane-operation rate)
   cpu_baseline  the compiled reference on the host cores, bounded sample.
 """
 from __future__ import annotations
@@ -49,6 +52,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md §HBM
 L2_PEAK_GBPS = 34500.0          # aggregate L2 (8 XCDs x 4 MiB), same guide §L2
+LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9   # vector lane-operations per second: 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz
+# the useful lane-instructions of one test as the lean kernels code it (ISA counts): the reference's slab test of one box
+# (6 mul, 6 add, 2 max3, 2 min3, compare, select = 18) and its Moeller-Trumbore test of one triangle (2 cross, 4 dot, divide, ~45)
+BOX_TEST_LANE_OPS, TRI_TEST_LANE_OPS = 18, 45
+# waves per SIMD the kernels are built for (csrc/wavefront_kernels.inc: YART_LEAN_WAVES, YART_SHADE_WAVES): VALU-issue share of a
+# SIMD's cycles = valu_active_per_wave_cycle x resident waves
+KERNEL_WAVES_PER_SIMD = {"k_wf_extend_lean": 7, "k_wf_shadow_lean": 7, "k_wf_shade": 3}
 RMSE_TOL = 1e-3                 # BASELINE.json north_star
 
 
@@ -102,55 +112,94 @@ def kernel_base(name):
     return k
 
 
-def pmc_traffic(args):
-    """{kernel: {launches, read_bytes, write_bytes}} summed over ONE step of the workload, or None.
-    FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory side; FETCH_SIZE is doubled (gfx950 tallies 128-B read
-    requests at 64 B) exactly as MI355X_MICROARCH.md §HBM prescribes; Infinity-Cache hits are included."""
+def pmc_pass(args, counters, keep_name=None):
+    """One rocprofv3 --pmc child run of ONE un-timed step of the workload: {kernel: {counter: sum over its launches, "launches": n}},
+    or None (no profiler, the pass failed or did not finish)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
-    out = {}
     keep = os.path.join(ROOT, args.keep_pmc) if args.keep_pmc else None
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         env = dict(os.environ, TMPDIR="/tmp")
-        for counter, field, scale in (("FETCH_SIZE", "read_bytes", 2048.0), ("WRITE_SIZE", "write_bytes", 1024.0)):
-            d = os.path.join(td, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
-                   sys.executable or "python3", os.path.join(ROOT, "bench.py"), "--pmc-child",
-                   "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--depth", str(args.depth),
-                   "--tex", str(args.tex), "--sky", str(args.sky), "--flags", str(args.flags)]
-            # its own process group: should the pass hang, the profiler AND the python under it are ended together
+        d = os.path.join(td, "pass")
+        cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
+               sys.executable or "python3", os.path.join(ROOT, "bench.py"), "--pmc-child",
+               "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--depth", str(args.depth),
+               "--tex", str(args.tex), "--sky", str(args.sky), "--flags", str(args.flags)]
+        # its own process group: should the pass hang, the profiler AND the python under it are ended together
+        try:
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                    start_new_session=True)
+        except OSError:
+            return None
+        try:
+            so, se = proc.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
             try:
-                proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                        start_new_session=True)
+                os.killpg(proc.pid, signal.SIGKILL)
             except OSError:
-                return None
-            try:
-                so, se = proc.communicate(timeout=240)
-            except subprocess.TimeoutExpired:
-                try:
-                    os.killpg(proc.pid, signal.SIGKILL)
-                except OSError:
-                    pass
-                proc.wait()
-                sys.stderr.write(f"bench.py: rocprofv3 --pmc {counter} pass did not finish in 240 s; traffic = null\n")
-                return None
-            r = subprocess.CompletedProcess(cmd, proc.returncode, so, se)
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                sys.stderr.write(f"bench.py: rocprofv3 --pmc {counter} pass failed ({r.returncode}): {r.stderr.strip()[-300:]}\n")
-                return None
-            if keep:
-                os.makedirs(keep, exist_ok=True)
-                shutil.copy(files[0], os.path.join(keep, f"pmc_{counter.lower()}_counter_collection.csv"))
-            for row in csv.DictReader(open(files[0])):
-                k = kernel_base(row["Kernel_Name"])
-                if row["Counter_Name"] != counter or k is None:
-                    continue
-                e = out.setdefault(k, {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})
-                e[field] += float(row["Counter_Value"]) * scale
-                if counter == "FETCH_SIZE":
-                    e["launches"] += 1
+                pass
+            proc.wait()
+            sys.stderr.write(f"bench.py: rocprofv3 --pmc {' '.join(counters)} pass did not finish in 240 s\n")
+            return None
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if proc.returncode != 0 or not files:
+            sys.stderr.write(f"bench.py: rocprofv3 --pmc {' '.join(counters)} pass failed ({proc.returncode}): {se.strip()[-300:]}\n")
+            return None
+        if keep:
+            os.makedirs(keep, exist_ok=True)
+            shutil.copy(files[0], os.path.join(keep, f"pmc_{(keep_name or counters[0]).lower()}_counter_collection.csv"))
+        out = {}
+        seen = {}
+        for row in csv.DictReader(open(files[0])):
+            k = kernel_base(row["Kernel_Name"])
+            if k is None or row["Counter_Name"] not in counters:
+                continue
+            e = out.setdefault(k, {"launches": 0})
+            e[row["Counter_Name"]] = e.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            if (k, row["Dispatch_Id"]) not in seen:
+                seen[(k, row["Dispatch_Id"])] = True
+                e["launches"] += 1
+        return out
+
+
+def pmc_traffic(args):
+    """{kernel: {launches, read_bytes, write_bytes}} summed over ONE step of the workload, or None.
+    FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory side, collected in separate passes; FETCH_SIZE is doubled (gfx950 tallies
+    128-B read requests at 64 B) exactly as MI355X_MICROARCH.md §HBM prescribes; Infinity-Cache hits are included."""
+    out = {}
+    for counter, field, scale in (("FETCH_SIZE", "read_bytes", 2048.0), ("WRITE_SIZE", "write_bytes", 1024.0)):
+        r = pmc_pass(args, [counter])
+        if r is None:
+            return None
+        for k, v in r.items():
+            e = out.setdefault(k, {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})
+            e[field] += v.get(counter, 0.0) * scale
+            if counter == "FETCH_SIZE":
+                e["launches"] += v["launches"]
+    return out
+
+
+SQ_COUNTERS = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY"]
+
+
+def pmc_efficiency(args):
+    """{kernel: {lane_util, valu_active_per_wave_cycle, ...}} of ONE step of the timed workload (a third counter pass): how full the
+    64 lanes of the issued vector instructions are, and the share of a resident wave's cycles in which it issues one — the two figures
+    that the bandwidth fractions hide (a kernel at 0.4 of the L2 roof with half of its lanes idle)."""
+    r = pmc_pass(args, SQ_COUNTERS, keep_name="sq")
+    if r is None:
+        return None
+    out = {}
+    for k, v in r.items():
+        act, wc = v.get("SQ_ACTIVE_INST_VALU", 0.0), v.get("SQ_WAVE_CYCLES", 0.0)
+        if act <= 0 or wc <= 0:
+            continue
+        out[k] = {"lane_util": round(v.get("SQ_THREAD_CYCLES_VALU", 0.0) / (act * 64.0), 4),
+                  "valu_active_per_wave_cycle": round(act / wc, 4),
+                  "wait_inst_per_wave_cycle": round(v.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+                  "valu_wave_instructions": int(v.get("SQ_INSTS_VALU", 0.0)), "salu_wave_instructions": int(v.get("SQ_INSTS_SALU", 0.0)),
+                  "launches": v["launches"]}
     return out
 
 
@@ -308,9 +357,10 @@ def main():
     # counter passes first: child processes, started before this process has initialised the GPU. At N > 1 they are
     # left out (a profiler child on GPU 0 while seven other ranks hold their devices is not a combination to try on
     # a shared node): `traffic` is then null and the N = 1 line / profiles/ carry the memory-side bytes.
-    pmc = None
+    pmc = eff = None
     if world == 1 and not args.no_roofline and not args.no_pmc and not under_profiler():
         pmc = pmc_traffic(args)
+        eff = pmc_efficiency(args)
 
     import numpy as np
     import torch
@@ -500,9 +550,7 @@ def main():
             e = {"kernel": k, "bound": "l2", "peak": L2_PEAK_GBPS, "avg_launch_ms": round(t_l * 1e3, 3), "launches_per_step": n_l,
                  "model": "(32 B x box tests + 52 B x triangle tests + 48 B) per ray (SURVEY §8(d) B_traversal); the BVH is cache "
                           "resident, so the roof is the L2's bandwidth, not HBM's",
-                 "note": "instruction issue, L1 requests and rays in flight are in balance, none alone is the bound: 16 % fewer VALU "
-                         "instructions per step buy 1 %, 38 % fewer L1 requests 0-2 %, 4 instead of 7 waves cost 13 % (profiles/r3_ab_top_cache.txt); "
-                         "TA busy 0.84, VALU issuing ~0.7 of the time (profiles/r3_mem_path_counters.txt, r3_pmc_sq_summary.txt)",
+                 "useful_lane_ops_per_launch": int((BOX_TEST_LANE_OPS * box + TRI_TEST_LANE_OPS * tri) / n_l),
                  "kernel_tally_bytes_per_launch": int(own / n_l),
                  "kernel_tally_per_ray": {"box": round(box / max(1, trav), 2), "tri": round(tri / max(1, trav), 2)},
                  "rays_per_step": trav, "rays_handed_to_general_kernel": retried}
@@ -529,6 +577,18 @@ def main():
             if tr and t > 0:
                 e["traffic_GBps"] = round(e["traffic"] / t * 1e-9, 1)
                 e["traffic_frac_of_hbm_peak"] = round(e["traffic"] / t * 1e-9 / HBM_PEAK_GBPS, 4)
+            ef = eff.get(e["kernel"]) if eff else None
+            if ef:
+                # how full the issued vector instructions are, and how much of the time the SIMDs issue them
+                e["lane_util"] = ef["lane_util"]
+                e["valu_active_per_wave_cycle"] = ef["valu_active_per_wave_cycle"]
+                w = KERNEL_WAVES_PER_SIMD.get(e["kernel"])
+                if w:
+                    e["valu_busy"] = round(min(1.0, ef["valu_active_per_wave_cycle"] * w), 4)
+                e["valu_wave_instructions_per_launch"] = ef["valu_wave_instructions"] // max(1, ef["launches"])
+            if "useful_lane_ops_per_launch" in e and t > 0:
+                # the VALU-side fraction: lane-operations of the box and triangle tests alone against the peak lane-operation rate
+                e["valu_frac"] = round(e["useful_lane_ops_per_launch"] / t / LANE_OPS_PEAK, 4)
             if world > 1:
                 e["share"] = f"rank 0 of {world}"
         dominant = max(entries, key=lambda e: e["avg_launch_ms"] * e["launches_per_step"])
@@ -536,6 +596,10 @@ def main():
         out["rooflines"] = entries
         out["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this workload, this build, this box "
                                  "(FETCH_SIZE x 2 per MI355X_MICROARCH.md)") if pmc else None
+        out["efficiency_source"] = ("rocprofv3 --pmc " + " ".join(SQ_COUNTERS) + ": one more child run of this workload; lane_util = "
+                                    "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x "
+                                    "waves per SIMD, valu_frac = (18 x box tests + 45 x triangle tests) lane-ops / launch time / "
+                                    "39.3 T lane-ops/s") if eff else None
         out["stage_ms_per_step"] = {k: round(last[k], 2) for k in
                                     ("ms_extend", "ms_extend_lean", "ms_connect", "ms_shadow_lean", "ms_shade", "ms_shade_kernel", "ms_gmon", "ms_device")}
         out["counts_per_step"] = {k: c[k] for k in ("traversals", "box_tests", "tri_tests", "shaded_hits")}

@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline / parity sample")
     ap.add_argument("--ref-order-spp", type=int, default=1, help="spp of the oracle run that counts box / triangle tests in the reference's traversal order")
     ap.add_argument("--flags", type=int, default=0, help="YART_FLAG_* pipeline variant (A/B experiments)")
+    ap.add_argument("--inproc", action="store_true",
+                    help="time the in-process form instead: ONE process, yart_hip_multi_render over --gpus devices (a host thread per "
+                         "device, the devices' own pixels merged on device 0 with RCCL send / recv: 1/N of the frame's bytes)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # one un-timed step, no torch (run under rocprofv3 --pmc)
     ap.add_argument("--dry-launch", action="store_true",
                     help="no GPU: start the --gpus N ranks with gloo and reduce synthetic frames (launch-path rehearsal)")
@@ -278,6 +281,40 @@ def visible_gpu_count():
     return n
 
 
+def inproc_run(args):
+    """--inproc: the frame rendered by ONE process on --gpus devices through yart_hip_multi_render (csrc/multi_device.inc: one host
+    thread per device, pixel blocks dealt round-robin, every device's own pixels sent to device 0 with grouped RCCL send / recv —
+    1/N of the frame per device instead of the whole-frame reduce(SUM) of the process-per-GPU form) — the same workload, warm-up
+    and step count; the frame is delivered to a host buffer each step, as the C ABI's blocking entry does. Prints one JSON line."""
+    import numpy as np
+    from yart_amd import api
+    n = args.gpus
+    one = bool(os.environ.get("YART_BENCH_ONE_DEVICE"))          # rehearsal on a one-GPU box: every replica on device 0 (peer copies, no RCCL)
+    if not one and visible_gpu_count() < n:
+        sys.stderr.write(f"bench.py: --inproc --gpus {n} but only {visible_gpu_count()} HIP device(s) are visible\n")
+        return 2
+    scene, p = workload(args)
+    p = dict(p, shard_tile=16 if n > 1 else 0)
+    ms = api.MultiDeviceScene(scene, [0] * n if one else list(range(n)))
+    for _ in range(args.warmup):
+        ms.render(p, flags=args.flags)
+    t0 = time.perf_counter()
+    st = {}
+    for _ in range(args.steps):
+        img, st = ms.render(p, flags=args.flags)
+    dt = time.perf_counter() - t0
+    W, H = p["size"]
+    out = {"metric": "Msamples/sec (W*H*spp/s), Sponza-class 1080p 8-bounce", "value": round(W * H * p["spp"] * args.steps / dt * 1e-6, 3),
+           "unit": "Msamples/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mode": "inproc",
+           "config": {"workload": "sponza_class (generated atrium, %d triangles, env-lit) %dx%d, %d spp, %d bounces" % (scene.n_triangles, W, H, p["spp"], p["depth"]),
+                      "parallelism": f"tiles/{n}: one process, yart_hip_multi_render ({'every replica on device 0: rehearsal' if one else 'one device per replica'}), "
+                                     "slab merge on device 0, frame copied to the host every step"},
+           "rays_per_step": int(st.get("rays", 0)), "frame_checksum": float(np.nan_to_num(img[..., :3]).sum(dtype=np.float64))}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def self_launch(args):
     """--gpus N > 1 (or --dry-launch) without torchrun's environment: start the N ranks as children of THIS process,
     which has not touched the GPU, relay their output (rank 0 prints the JSON line) and return the launcher's code."""
@@ -341,6 +378,8 @@ def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args)
+    if args.inproc:
+        return inproc_run(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (args.gpus != 1 or args.dry_launch):
         return self_launch(args)
@@ -450,6 +489,7 @@ def main():
         mine["reduce_ms"] = round(sum(a.elapsed_time(b) for a, b in reduce_ev) / max(1, len(reduce_ev)), 3)
         mine["rank"] = rank
         mine["samples"] = int(last.get("samples", 0))
+        mine["paths_at_bounce"] = [int(x) for x in last.get("paths_at_bounce", [])][: p["depth"] + 1]   # this rank's live paths per bounce
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
@@ -468,6 +508,7 @@ def main():
                                   "blocks sharded by rank inside the library, one reduce(SUM) of the frame to rank 0 per step",
                    "pipeline_flags": int(last.get("pipeline_flags", args.flags))},
         "rays_per_step": int(last.get("rays", 0)),
+        "paths_at_bounce": [int(x) for x in last.get("paths_at_bounce", [])][: p["depth"] + 1],     # rank 0's live paths entering each bounce
     }
     if per_rank is not None:
         slow = max(per_rank, key=lambda r: r["ms_device"])

@@ -205,6 +205,9 @@ typedef struct YartStats {
      reference's leaf box, [3] ray outside the trees' guard (non-finite slab set-up, origin bound) or NaN t */
   uint64_t wide_extend_nodes, wide_extend_tris, wide_shadow_nodes, wide_shadow_tris;
   uint64_t wide_extend_handed[4], wide_shadow_handed[4];
+  /* ABI 3, batch-synchronous wavefront pipeline: paths of this rank that entered bounce b (b < 16; [0] = every path), summed over
+     the batches: how the work of a rank decays with the depth (an imbalance between ranks shows here first) */
+  uint64_t paths_at_bounce[16];
 } YartStats;
 
 typedef struct YartScene YartScene;

@@ -82,6 +82,18 @@ def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
 
 
+def test_bench_inproc_refuses_without_the_devices():
+    """--inproc (one process, yart_hip_multi_render over N devices) refuses to run on fewer devices than asked."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    if bench.visible_gpu_count() >= 2:
+        pytest.skip("two devices are visible: the refusal cannot be provoked here")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "YART_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--inproc"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "--inproc" in r.stderr
+
+
 def test_bench_cpu_baseline_leg_runs_on_a_small_case():
     """bench.py's cpu_baseline leg (the compiled reference, or the oracle, timed on the host cores) on a 32x32 case,
     with the library-only keys the bench carries in its parameter dict: the timing entry, the frame the parity gate

@@ -390,3 +390,26 @@ def test_path_pool_sizes(api):
         assert int(st["rays"]) == int(st0["rays"]), q
         assert st["pipeline_flags"] & 512
     scene.close()
+
+
+def test_bench_inproc_mode_rehearsal(api):
+    """bench.py --inproc (one process, yart_hip_multi_render over N devices) on a small frame with both replicas on device 0
+    (YART_BENCH_ONE_DEVICE: peer copies instead of RCCL): one JSON line, the frame's checksum equal to a single-device render's,
+    and the per-bounce path counts of YartStats add up."""
+    import sys
+    from yart_amd import scenes
+    env = dict(os.environ, YART_BENCH_ONE_DEVICE="1")
+    args = ["--width", "96", "--height", "54", "--spp", "4", "--depth", "4", "--tex", "32", "--sky", "32", "--steps", "1", "--warmup", "0"]
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "..", "bench.py"), "--gpus", "2", "--inproc"] + args,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["mode"] == "inproc" and line["n_gpus"] == 2 and line["value"] > 0
+    s, p = scenes.sponza_class(96, 54, 4, 4, tex=32, sky=32)
+    scene = api.DeviceScene(s, device=0)
+    img, st = scene.render(p)
+    assert float(np.nan_to_num(img[..., :3]).sum(dtype=np.float64)) == line["frame_checksum"]
+    assert int(st["rays"]) == line["rays_per_step"]
+    pb = list(st["paths_at_bounce"])
+    assert pb[0] == 96 * 54 * 4 and all(pb[i] >= pb[i + 1] for i in range(4)) and pb[1] > 0 and pb[5] == 0
+    scene.close()

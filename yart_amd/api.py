@@ -130,7 +130,8 @@ class Stats(C.Structure):
                 ("retry_extend_traversals", C.c_uint64), ("retry_shadow_traversals", C.c_uint64),
                 ("wide_extend_nodes", C.c_uint64), ("wide_extend_tris", C.c_uint64),
                 ("wide_shadow_nodes", C.c_uint64), ("wide_shadow_tris", C.c_uint64),
-                ("wide_extend_handed", C.c_uint64 * 4), ("wide_shadow_handed", C.c_uint64 * 4)]
+                ("wide_extend_handed", C.c_uint64 * 4), ("wide_shadow_handed", C.c_uint64 * 4),
+                ("paths_at_bounce", C.c_uint64 * 16)]
 
     def asdict(self):
         return {k: _plain(getattr(self, k)) for k, _ in self._fields_}

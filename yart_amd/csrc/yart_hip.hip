@@ -369,6 +369,7 @@ struct YartScene {
   DevBuf<f4> wfTail[2][9];                 // compacted states of the late bounces (1/2 and 1/4 of the batch)
   DevBuf<uint32_t> wfTailMap[2];
   DevBuf<WfDyn> wfDyn;
+  DevBuf<unsigned long long> pathsLog;     // paths entering bounce b, summed over the batches of a render (YartStats::paths_at_bounce)
   DevBuf<uint32_t> poolMap;                // path pool: the path (index of L) each slot carries, kWfFreeSlot = free
   uint32_t* poolHost = nullptr;            // pinned: the queue counters of the last rounds (the host's view of "is the batch done")
   ~YartScene() { if (poolHost) (void)hipHostFree(poolHost); }
@@ -588,7 +589,8 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
 
   const uint64_t startSample = p.start_sample, stopSample = p.stop_sample ? p.stop_sample : p.samples;
   if (startSample == 0) HIP_CHECK(hipMemsetAsync(dOut, 0, size_t(W) * H * 4 * sizeof(float), stream));
-  s.cursor.ensure(1); s.counters.ensure(kNumCounters);
+  s.cursor.ensure(1); s.counters.ensure(kNumCounters); s.pathsLog.ensure(16);
+  HIP_CHECK(hipMemsetAsync(s.pathsLog.p, 0, 16 * sizeof(unsigned long long), stream));
   HIP_CHECK(hipMemsetAsync(s.counters.p, 0, kNumCounters * sizeof(unsigned long long), stream));
 #if defined(YART_COUNT_TRAVERSAL)
   { const unsigned long long zero = 0; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_texTapBytes), &zero, sizeof(zero))); }
@@ -941,7 +943,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             HIP_CHECK(hipGetLastError());
             tShade.end(stream);
           }
-          hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
+          hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(64), 0, stream, s.wfCounters.p, bounce + 1 < 16u ? s.pathsLog.p + bounce + 1 : nullptr);
           HIP_CHECK(hipGetLastError());
           std::swap(a.qA, a.qB);
           if (compact && bounce >= 1 && bounce + 1 < rc.maxDepth) {     // Russian roulette starts thinning at depth 2
@@ -1012,6 +1014,12 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     stats->wide_extend_nodes = cnt[10]; stats->wide_extend_tris = cnt[11]; stats->wide_shadow_nodes = cnt[12]; stats->wide_shadow_tris = cnt[13];
     for (int k = 0; k < 4; k++) { stats->wide_extend_handed[k] = cnt[14 + k]; stats->wide_shadow_handed[k] = cnt[18 + k]; }
     stats->pipeline_flags = effFlags;
+    {
+      unsigned long long pl[16] = {0};
+      HIP_CHECK(hipMemcpy(pl, s.pathsLog.p, sizeof(pl), hipMemcpyDeviceToHost));
+      for (int b = 0; b < 16; b++) stats->paths_at_bounce[b] = pl[b];
+      stats->paths_at_bounce[0] = mega || pool ? 0 : uint64_t(nPix) * renderedSamples;     // (every path enters bounce 0)
+    }
 #if defined(YART_COUNT_TRAVERSAL)
     {
       unsigned long long tb = 0;

@@ -345,6 +345,9 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
           hasAlpha[n] = hasAlpha[bn.leftFirst] | hasAlpha[bn.leftFirst + 1];
         }
         if (hasAlpha[n]) im.bvhNodes[md.nodeOffset + n].leftFirst |= kLinkAlphaBit;
+        // ... and the node's span, saturated, in the link word's top bits: what the traversal keeps of a node (its stack entries,
+        // the lean inner step's `cur`) is this word as loaded — no pack per step (traverse.hpp::packLink is idempotent on it)
+        im.bvhNodes[md.nodeOffset + n].leftFirst |= (bn.span < kSpanBig ? bn.span : kSpanBig) << kSpanShift;
       }
       md.hasAlpha = hasAlpha.empty() ? 0u : hasAlpha[0];
     }

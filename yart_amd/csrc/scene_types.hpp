@@ -61,7 +61,7 @@ struct MaterialDev {       // bsdf/parametric.hpp:52-77
   float pad[2];
 };
 
-// BvhNode::leftFirst as stored for the device: bits 0..25 the reference's index (left child / first
+// BvhNode::leftFirst as stored for the device (the traversal's LINK WORD): bits 27..31 min(span, 31), bits 0..25 the reference's index (left child / first
 // leaf triangle), bit 26 set when the node's subtree contains a triangle with an alpha-tested
 // material (used by the lean shadow kernel to end occluded rays early, traverse.hpp).
 constexpr uint32_t kLinkIndexMask = (1u << 26) - 1u;

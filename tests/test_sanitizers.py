@@ -36,3 +36,7 @@ def test_host_build_is_clean_under_asan_and_ubsan(san, tmp_path):
     r = subprocess.run([san, "render", base + ".yscn", base + ".txt", out], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-800:]
     assert np.array_equal(np.fromfile(out, np.uint32), np.fromfile(base + ".f32", np.uint32))
+    # the 8-wide tree build (bvh8_build.hpp) and the scalar form of its walk (traverse_wide.hpp) on a scene with both trees
+    r = subprocess.run([san, "widecheck", base + ".yscn", base + ".txt", "24", "16", "4"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-800:]
+    assert '"widecheck": "ok"' in r.stdout

@@ -211,6 +211,7 @@ YART_HD bool wfRouletteAfterShadow(const RenderConst& rc, const WfState& s, uint
   return false;
 }
 
+
 // What a finished shadow ray leaves behind (mis-integrator.cpp:125-133 + the caller's `L += attenuation * Ld`, :80):
 // unoccluded -> L += attPre * (Lif * attOcc * cos / denom), one more ray; occluded -> L += attPre * 0, which only a non-finite
 // throughput makes visible (WF_ATT_NAN); a path whose bounce budget is used up (WF_FINAL) is written out here.

@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline / parity sample")
     ap.add_argument("--ref-order-spp", type=int, default=1, help="spp of the oracle run that counts box / triangle tests in the reference's traversal order")
     ap.add_argument("--flags", type=int, default=0, help="YART_FLAG_* pipeline variant (A/B experiments)")
+    ap.add_argument("--batch-paths", type=int, default=-1,
+                    help="YartRenderParams::max_batch_paths: -1 (default) = the whole frame as one batch, 0 = the library's default (2^28)")
     ap.add_argument("--inproc", action="store_true",
                     help="time the in-process form instead: ONE process, yart_hip_multi_render over --gpus devices (a host thread per "
                          "device, the devices' own pixels merged on device 0 with RCCL send / recv: 1/N of the frame's bytes)")
@@ -91,8 +93,15 @@ def parse():
 
 
 def workload(args):
+    """The scene and the render parameters. `--batch-paths` (default: the frame's own path count, i.e. ONE batch — how rounds 1-3
+    measured this workload; 152 GB of path state on the 288 GB device for the 1080p x 256 spp frame) sets
+    YartRenderParams::max_batch_paths; 0 = the library's default, a fixed 2^28 paths per batch (77 GB; this frame then takes two
+    batches and ~10 ms more: profiles/r4_batch_sweep.txt). The frame does not depend on it."""
     from yart_amd import scenes
-    return scenes.sponza_class(args.width, args.height, args.spp, args.depth, tex=args.tex, sky=args.sky)
+    scene, p = scenes.sponza_class(args.width, args.height, args.spp, args.depth, tex=args.tex, sky=args.sky)
+    frame = args.width * args.height * args.spp
+    p["max_batch_paths"] = min(frame, (1 << 31) - 64) if args.batch_paths < 0 else args.batch_paths
+    return scene, p
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -128,7 +137,7 @@ def pmc_pass(args, counters, keep_name=None):
         cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
                sys.executable or "python3", os.path.join(ROOT, "bench.py"), "--pmc-child",
                "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--depth", str(args.depth),
-               "--tex", str(args.tex), "--sky", str(args.sky), "--flags", str(args.flags)]
+               "--tex", str(args.tex), "--sky", str(args.sky), "--flags", str(args.flags), "--batch-paths", str(args.batch_paths)]
         # its own process group: should the pass hang, the profiler AND the python under it are ended together
         try:
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
@@ -506,7 +515,11 @@ def main():
                    "pipeline": "megakernel" if args.flags & 1 else "wavefront", "tiles": f"{shard or 64}x{shard or 64} pixel blocks, Morton order, round-robin over ranks",
                    "parallelism": f"tiles/{n_ranks}: one process per GPU (torch.distributed, backend {backend if world > 1 else 'none'}), "
                                   "blocks sharded by rank inside the library, one reduce(SUM) of the frame to rank 0 per step",
-                   "pipeline_flags": int(last.get("pipeline_flags", args.flags))},
+                   "pipeline_flags": int(last.get("pipeline_flags", args.flags)),
+                   "max_batch_paths": int(p.get("max_batch_paths", 0)),
+                   "batches": "the frame is one batch (max_batch_paths = its path count); the library's default of 2^28 paths per batch "
+                              "renders it in two, +1.4 % (profiles/r4_batch_sweep.txt)" if p.get("max_batch_paths", 0) >= W * H * p["spp"]
+                              else "max_batch_paths = %d" % int(p.get("max_batch_paths", 0))},
         "rays_per_step": int(last.get("rays", 0)),
         "paths_at_bounce": [int(x) for x in last.get("paths_at_bounce", [])][: p["depth"] + 1],     # rank 0's live paths entering each bounce
     }

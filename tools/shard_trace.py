@@ -7,7 +7,7 @@ from yart_amd import api, scenes
 world = int(os.environ.get("WORLD", "1"))
 scene, p = scenes.sponza_class(1920, 1080, 256, 8, tex=1024, sky=2048)
 ds = api.DeviceScene(scene, device=0)
-q = dict(p, shard_tile=16 if world > 1 else 0)
+q = dict(p, shard_tile=16 if world > 1 else 0, max_batch_paths=1920 * 1080 * 256)    # (the whole frame: one batch)
 for _ in range(2):
     _, st = ds.render(q, rank=0, world_size=world)
 print(world, round(st["ms_device"], 2))

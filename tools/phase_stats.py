@@ -10,7 +10,7 @@ flags = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 img, st = ds.render(p, flags=flags)
 c = ds.debug_counters()
 names = ["outer", "walk-node", "inner/pop", "tri", "slowpath", "leaf", "refill"] if flags == 2 else \
-        ["inner/pop", "tri", "leaf-visit", "walk-step", "mask-box", "outer-round", "refill"]
+        ["inner/pop", "tri", "leaf-visit", "walk-step", "mask-box", "outer-round", "refill", "box-pair"]
 print("ms extend %.1f connect %.1f" % (st["ms_extend"], st["ms_connect"]))
 for k, n in enumerate(names):
     it, act = c[8 + 2 * k], c[9 + 2 * k]

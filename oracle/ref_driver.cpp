@@ -214,6 +214,14 @@ static int doRender(const std::string& scenePath, const std::string& paramPath,
   r.maxWaveSamples = p.maxWave;
   r.tileSize = p.tile;
   if (p.threads) r.threadCount = p.threads;
+  else {
+    // No thread count asked for: at most one worker per four tiles (at least one). TileRenderer's workers read m_currentWave
+    // without the lock (tile-renderer.hpp:160-190); a worker that only starts when two short waves are already over waits for a
+    // wave number that has passed, and renderSync() never returns — seen with one-tile frames on a many-core host (2 of 4000).
+    const uint32_t ts = p.tile ? p.tile : 64u;
+    const uint64_t tiles = uint64_t((p.width + ts - 1) / ts) * ((p.height + ts - 1) / ts);
+    r.threadCount = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(r.threadCount, tiles / 4)));
+  }
   r.backgroundColor = float3(p.background[0], p.background[1], p.background[2]);
 
   auto t0 = std::chrono::high_resolution_clock::now();

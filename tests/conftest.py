@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 HOSTSIM = os.path.join(ROOT, "tests", "hostsim", "_build", "hostsim")
+HOSTSIM_LEAN = os.path.join(ROOT, "tests", "hostsim", "_build", "hostsim_lean")
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "yart_ref")
 ORACLE_BIN = os.path.join(ROOT, "oracle", "_build", "yart_oracle")
 
@@ -19,7 +20,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def built():
     """Native targets exist (build() is idempotent and cheap when up to date)."""
-    if not (os.path.exists(os.path.join(ROOT, "yart_amd", "libyart_hip.so")) and os.path.exists(HOSTSIM)):
+    if not (os.path.exists(os.path.join(ROOT, "yart_amd", "libyart_hip.so")) and os.path.exists(HOSTSIM) and os.path.exists(HOSTSIM_LEAN)):
         import __graft_entry__
         __graft_entry__.build()
     return True
@@ -28,6 +29,13 @@ def built():
 @pytest.fixture(scope="session")
 def hostsim(built):
     return HOSTSIM
+
+
+@pytest.fixture(scope="session")
+def hostsim_lean(built):
+    """hostsim whose path tracer runs the lean kernels' hand-over logic (TRAV_FAST walk first, general walk for the rays it hands
+    over) and reports on stderr every ray it keeps whose result differs from the general walk's."""
+    return HOSTSIM_LEAN
 
 
 def run(cmd, **kw):

@@ -1,0 +1,38 @@
+"""GPU-box experiment: tests/test_fuzz_scenes.py's comparison over a wider range of seeds (FIRST LAST), every pipeline variant of
+tests/test_gpu_parity.py::PIPELINE_FLAGS, against the compiled reference (oracle/_ref/yart_ref). Prints one line per mismatch."""
+import faulthandler, os, subprocess, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from yart_amd import api, scenes
+from tests.test_gpu_parity import PIPELINE_FLAGS
+REF = os.path.join(ROOT, "oracle", "_ref", "yart_ref")
+first, last = int(sys.argv[1]), int(sys.argv[2])
+tmp = tempfile.mkdtemp()
+bad = 0; ref_hangs = 0; frames = 0; nan_frames = 0; t0 = time.time()
+for seed in range(first, last):
+    s, p = scenes.random_scene(seed, 64, 48, 4 if seed % 3 else 16, 6 if seed % 4 else 12)
+    sp, pp, rf = f"{tmp}/s.yscn", f"{tmp}/p.txt", f"{tmp}/r.f32"
+    s.save(sp); scenes.write_params(pp, p, threads=1)     # (one worker: see _reference_frame's note in tests/test_fuzz_scenes.py)
+    try:
+        subprocess.run([REF, "render", sp, pp, rf], check=True, stdout=subprocess.DEVNULL, timeout=120)
+    except subprocess.TimeoutExpired:
+        print(f"seed {seed}: the REFERENCE did not finish within 120 s (skipped)", flush=True); ref_hangs += 1
+        continue
+    ref = np.fromfile(rf, np.uint32)
+    nan_frames += int(np.isnan(ref.view(np.float32)).any())
+    ds = api.DeviceScene(s, device=0)
+    for name, flags in PIPELINE_FLAGS.items():
+        faulthandler.dump_traceback_later(90, exit=True)       # a render that does not return: say where, and stop
+        print(f"seed {seed} {name}", file=open(os.path.join(tmp, "last"), "w"))
+        img, _ = ds.render(p, flags=flags)
+        faulthandler.cancel_dump_traceback_later()
+        g = np.ascontiguousarray(img, np.float32).view(np.uint32).ravel()
+        frames += 1
+        if not np.array_equal(ref, g):
+            bad += 1
+            print(f"MISMATCH seed {seed} / {name}: {(ref != g).sum()} of {ref.size} words differ", flush=True)
+    ds.close()
+    if seed % 25 == 0: print(f"seed {seed} done, {time.time() - t0:.0f} s", flush=True)
+print(f"seeds {first}..{last - 1}: {frames} frames of {len(PIPELINE_FLAGS)} pipelines, {bad} differ from the reference's; "
+      f"{nan_frames} reference frames hold a NaN; the reference itself hung on {ref_hangs} seeds")

@@ -79,6 +79,24 @@ YART_HD bool unoccluded(const PathCtx& cx, Sampler& smp, f3 from, f3 to, f3& att
   hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
   attenuation = mk3(1.0f);
   AlphaCtx ac; ac.sampler = &smp; ac.cfg = cx.rc.sampler;
+#if defined(YART_EMULATE_LEAN_HANDOVER)
+  {   // host tests only (tests/hostsim): the lean kernels' walk first; a ray it hands over is traced again by the general walk
+    HitRec hl = hr; f3 al = mk3(1.0f);
+    AlphaCtx af; af.sampler = nullptr; af.cfg = SamplerConfig{};
+    const bool occl = traverseScene<true, TRAV_FAST>(*cx.sc, from, dir, 0.001f, hl, al, cx.stk, af);
+#if defined(YART_EMULATE_LEAN_DEBUG)
+    if (!af.deferred) {
+      Sampler sc2 = smp; HitRec hg = hr; f3 ag = mk3(1.0f);
+      AlphaCtx ax; ax.sampler = &sc2; ax.cfg = cx.rc.sampler;
+      const bool og = traverseScene<true>(*cx.sc, from, dir, 0.001f, hg, ag, cx.stk, ax);
+      if (og != occl || sc2.dim != smp.dim || (!og && (ag.x != al.x || ag.y != al.y || ag.z != al.z)))
+        std::fprintf(stderr, "SHADOW differs: lean occl %d t %.9g tri %u node %u | general occl %d t %.9g tri %u node %u draws %u att %g %g %g | from %.9g %.9g %.9g dir %.9g %.9g %.9g tmax %.9g\n",
+                     int(occl), hl.t, hl.tri, hl.node, int(og), hg.t, hg.tri, hg.node, sc2.dim - smp.dim, ag.x, ag.y, ag.z, from.x, from.y, from.z, dir.x, dir.y, dir.z, hr.t);
+    }
+#endif
+    if (!af.deferred) { attenuation = al; return !occl; }
+  }
+#endif
   bool occluded = traverseScene<true>(*cx.sc, from, dir, 0.001f, hr, attenuation, cx.stk, ac);
   YART_FOLD_COUNTS(cx, ac);
   return !occluded;
@@ -119,7 +137,28 @@ YART_HD f3 pathRadiance(const PathCtx& cx, Sampler& smp, f3 ro, f3 rd, uint32_t&
     hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
     f3 dummy = mk3(1.0f);
     AlphaCtx ac; ac.sampler = &smp; ac.cfg = cx.rc.sampler;
-    bool didHit = traverseScene<false>(sc, ro, rd, 0.001f, hr, dummy, cx.stk, ac);
+    bool didHit;
+#if defined(YART_EMULATE_LEAN_HANDOVER)
+    {
+      HitRec hl = hr; f3 al = mk3(1.0f);
+      AlphaCtx af; af.sampler = nullptr; af.cfg = SamplerConfig{};
+      const bool h = traverseScene<false, TRAV_FAST>(sc, ro, rd, 0.001f, hl, al, cx.stk, af);
+#if defined(YART_EMULATE_LEAN_DEBUG)
+      if (!af.deferred) {
+        Sampler sc2 = smp; HitRec hg = hr; f3 ag = mk3(1.0f);
+        AlphaCtx ax; ax.sampler = &sc2; ax.cfg = cx.rc.sampler;
+        const bool g = traverseScene<false>(sc, ro, rd, 0.001f, hg, ag, cx.stk, ax);
+        if (g != h || sc2.dim != smp.dim || (g && (hg.t != hl.t || hg.tri != hl.tri || hg.node != hl.node || hg.u != hl.u)))
+          std::fprintf(stderr, "EXTEND differs: lean hit %d t %.9g tri %u node %u | general hit %d t %.9g tri %u node %u draws %u | o %.9g %.9g %.9g d %.9g %.9g %.9g\n",
+                       int(h), hl.t, hl.tri, hl.node, int(g), hg.t, hg.tri, hg.node, sc2.dim - smp.dim, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+      }
+#endif
+      if (!af.deferred) { hr = hl; didHit = h; }
+      else didHit = traverseScene<false>(sc, ro, rd, 0.001f, hr, dummy, cx.stk, ac);
+    }
+#else
+    didHit = traverseScene<false>(sc, ro, rd, 0.001f, hr, dummy, cx.stk, ac);
+#endif
     YART_FOLD_COUNTS(cx, ac);
     if (!didHit) {
       for (uint32_t k = 0; k < sc.nInfinite; k++) {

@@ -186,8 +186,9 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
   // Lean shadow kernel only (NEE && TRAV_FAST): once the ray is known to be occluded, the rest of
   // the reference's walk can only matter through alpha tests (sampler draws); subtrees without
   // alpha-tested triangles are skipped, and an alpha candidate hands the ray to the general kernel
-  // as before. Skipped subtrees could only have lowered hit.t, i.e. the walk visits a superset of
-  // the alpha candidates the reference tests: never a missed hand-over, at worst a spurious one.
+  // as before. From the first hit on the walk keeps its interval and looks at every triangle of the
+  // leaves it visits (see the leaf loop's end): a superset of the alpha candidates the reference
+  // tests — never a missed hand-over, at worst a spurious one.
   constexpr bool kPrune = NEE && (MODE & TRAV_FAST);
   const BvhNode* nodes = sc.bvhNodes + mesh.nodeOffset;
   const LeafTri* leaves = sc.leafTris + mesh.leafOffset;
@@ -263,6 +264,8 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
           actx.deferred = true;
           return false;
         }
+        // (lean shadow walk, already occluded: the interval stays what it was at the first hit — see the leaf loop's end)
+        if (kPrune && (occludedBefore || didHit)) break;
         if (!(MODE & TRAV_FAST) && (tr.matFlags & (MAT_HAS_ALPHA | MAT_TRANSPARENT))) {
           // slow path: alpha cut-outs and NEE-transparent surfaces
           f2 uv; f3 n;
@@ -282,7 +285,14 @@ YART_HD bool traverseMesh(const SceneDev& sc, const MeshDev& mesh, uint32_t node
         accepted = true;
       } while (false);
       didHit |= accepted;
-      if (NEE && didHit) break;
+      // The reference leaves a leaf's loop after the first triangle once the shadow ray has a hit IN THIS MESH. The lean shadow
+      // walk does so only at the hit itself (up to there it IS the reference's walk); from then on it looks for alpha candidates in
+      // a superset of what the reference can still test: every triangle of every leaf it visits, in the interval as it stood at
+      // the first hit. It accepts nothing further — a later hit is one the reference may never test (its own interval is
+      // shorter by then, or it is past the first triangle of a leaf), and accepting it would shorten the interval below the
+      // reference's or start the first-triangle rule in a mesh where the reference still tests every triangle: alpha candidates
+      // the reference draws for would then go unseen (found by the scene fuzz, tests/test_fuzz_scenes.py).
+      if (NEE && (kPrune ? accepted : didHit)) break;
     }
     if (stackIdx == 0) break;
     uint32_t link;

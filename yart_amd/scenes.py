@@ -718,3 +718,125 @@ def stacked_leaves(width=96, height=96, spp=4, depth=4, stacks=(40, 32, 64, 31, 
     s.add_node(s.add_mesh(b.build()))
     s.create_area_lights()
     return s, p
+
+
+def random_scene(seed, width=64, height=48, spp=4, depth=6):
+    """Seeded random scene of the parity fuzz (tests/test_fuzz_scenes.py): every constructor argument of the reference's
+    ParametricBSDF (bsdf/parametric.hpp:16-37) drawn at random — with the end points 0 and 1 over-represented, they pick other
+    branches of parametric.cpp —, every texture kind at odd, non-square sizes (texture.hpp:105-161), alpha cut-outs, thin and
+    refractive transmission with volume absorption, emissive triangles with and without emission textures, a triangle soup next
+    to smooth shapes, instances under nested non-uniformly scaled and rotated nodes (ray-integrator.cpp:20-54), zero to two
+    infinite lights, pinhole and thin-lens cameras (camera.hpp:138-164). No two seeds share a code path mix; nothing is tuned
+    to look good."""
+    rng = np.random.RandomState(seed)
+    s = Scene()
+    U = rng.uniform
+
+    def pick(*vals):
+        return vals[rng.randint(len(vals))]
+
+    def rtex(channels, typ, lo=0, hi=255):
+        h, w = int(rng.randint(2, 41)), int(rng.randint(2, 41))
+        if rng.rand() < 0.5:          # smooth: a few random texels blown up
+            g = rng.randint(lo, hi + 1, (int(rng.randint(1, 5)), int(rng.randint(1, 5)), channels))
+            yy = (np.arange(h) * g.shape[0] // h)[:, None]; xx = (np.arange(w) * g.shape[1] // w)[None, :]
+            data = g[yy, xx]
+        else:
+            data = rng.randint(lo, hi + 1, (h, w, channels))
+        return data.astype(np.uint8), typ
+
+    def add(data_typ):
+        return s.add_texture(Texture(*data_typ))
+
+    materials = []
+    n_mat = int(rng.randint(3, 11))
+    for k in range(n_mat):
+        m = Material(base=tuple(U(0.0, 1.0, 3)), metallic=float(pick(0.0, 0.0, 1.0, U(0, 1))),
+                     roughness=float(pick(0.0, 1.0, U(0, 1), U(0, 0.3))), transmission=float(pick(0.0, 0.0, 0.0, 1.0, U(0, 1))),
+                     ior=float(pick(1.5, 1.33, U(1.05, 2.4))), anisotropic=float(pick(0.0, 0.0, U(0, 1))),
+                     aniso_rotation=float(U(0, 1)), clearcoat=float(pick(0.0, 0.0, 1.0, U(0, 1))),
+                     clearcoat_roughness=float(pick(0.0, U(0, 0.6))), normal_scale=float(pick(1.0, U(0.2, 1.6))),
+                     thin_transmission=bool(rng.rand() < 0.4), volume_color=tuple(U(0.2, 1.0, 3)),
+                     volume_density=float(pick(0.0, U(0, 2.0))))
+        if rng.rand() < 0.2:
+            m.emission = tuple(U(0.5, 12.0, 3))
+        if rng.rand() < 0.4:
+            data, typ = rtex(4, TEX_SRGB)
+            if rng.rand() < 0.55:
+                data[..., 3] = 255                      # opaque: no alpha test
+            elif rng.rand() < 0.5:
+                data[..., 3] = np.where(data[..., 3] < 128, 0, 255)
+            m.tex_base = add((data, typ))
+        if rng.rand() < 0.35: m.tex_mr = add(rtex(2, TEX_NONCOLOR))
+        if rng.rand() < 0.3: m.tex_transmission = add(rtex(1, TEX_NONCOLOR))
+        if rng.rand() < 0.35: m.tex_normal = add(rtex(3, TEX_NONCOLOR, 64, 255))
+        if rng.rand() < 0.3: m.tex_clearcoat = add(rtex(1, TEX_NONCOLOR))
+        if m.is_emissive and rng.rand() < 0.5: m.tex_emission = add(rtex(3, TEX_SRGB))
+        materials.append(s.add_material(m))
+    M = lambda: materials[rng.randint(n_mat)]
+
+    def shapes(b, count, extent):
+        for _ in range(count):
+            c = U(-extent, extent, 3); c[1] = abs(c[1]) * 0.6 + 0.2
+            kind = rng.randint(4)
+            if kind == 0:
+                b.sphere(tuple(c), float(U(0.3, 1.2)), M(), nu=int(rng.randint(5, 14)), nv=int(rng.randint(3, 8)),
+                         uv_scale=(float(U(0.5, 3)), float(U(0.5, 3))))
+            elif kind == 1:
+                h = U(0.2, 1.0, 3)
+                b.box(tuple(c - h), tuple(c + h), M(), rot_y=float(U(0, 3.1)))
+            elif kind == 2:       # an upright card (cut-outs, thin glass)
+                a = U(0, 6.28); r = U(0.5, 1.6); t = np.array([math.cos(a), 0.0, math.sin(a)]) * r
+                up = np.array([0.0, U(0.6, 2.0), 0.0])
+                b.quad(tuple(c - t), tuple(c + t), tuple(c + t + up), tuple(c - t + up), M(), uv_scale=float(U(0.5, 3)))
+            else:                 # a triangle soup: random, partly degenerate-thin triangles with random shading normals
+                k = int(rng.randint(3, 40))
+                p = c + U(-1.0, 1.0, (k, 3, 3)) * U(0.05, 1.0, (k, 1, 1))
+                n = U(-1, 1, (k * 3, 3)); n /= np.linalg.norm(n, axis=-1, keepdims=True)
+                tg = U(-1, 1, (k * 3, 4)); tg[:, 3] = np.where(tg[:, 3] < 0, -1.0, 1.0)
+                b.add(p.reshape(-1, 3), n, tg, U(-2, 3, (k * 3, 2)), np.arange(k * 3).reshape(k, 3), M())
+
+    # the main mesh: a floor (sometimes a closed room) + shapes
+    b = MeshBuilder()
+    L = float(U(4.0, 9.0))
+    fm = M()
+    b.grid(lambda A, B: ((A - 0.5) * 2 * L, 0 * A, (B - 0.5) * 2 * L), int(rng.randint(1, 7)), int(rng.randint(1, 7)), fm,
+           uv_scale=(float(U(1, 5)), float(U(1, 5))), flip=True)
+    if rng.rand() < 0.4:
+        H = float(U(4.0, 8.0)); wm = M()
+        b.quad((-L, 0, -L), (L, 0, -L), (L, H, -L), (-L, H, -L), wm)
+        b.quad((-L, 0, L), (-L, 0, -L), (-L, H, -L), (-L, H, L), M())
+        b.quad((L, 0, -L), (L, 0, L), (L, H, L), (L, H, -L), M())
+        if rng.rand() < 0.5: b.quad((-L, H, -L), (L, H, -L), (L, H, L), (-L, H, L), wm)
+    shapes(b, int(rng.randint(2, 9)), L * 0.6)
+    s.add_node(s.add_mesh(b.build()), 0, *trs(tuple(U(-0.5, 0.5, 3)), tuple(U(-1, 1, 3) + 1e-3), float(pick(0.0, U(-0.3, 0.3))),
+                                               pick((1, 1, 1), tuple(U(0.7, 1.4, 3)))))
+    # instanced meshes under nested nodes
+    for _ in range(int(rng.randint(0, 4))):
+        bb = MeshBuilder()
+        shapes(bb, int(rng.randint(1, 4)), 1.0)
+        mesh = s.add_mesh(bb.build())
+        parent = 0
+        for _level in range(int(rng.randint(0, 3))):
+            parent = s.add_node(-1, parent, *trs(tuple(U(-2, 2, 3)), tuple(U(-1, 1, 3) + 1e-3), float(U(-3.1, 3.1)),
+                                                 tuple(U(0.5, 1.6, 3))))
+        for _inst in range(int(rng.randint(1, 4))):
+            t = U(-L * 0.5, L * 0.5, 3); t[1] = abs(t[1]) * 0.3
+            s.add_node(mesh, parent, *trs(tuple(t), tuple(U(-1, 1, 3) + 1e-3), float(U(-3.1, 3.1)),
+                                          pick(tuple(U(0.4, 1.8, 3)), (1, 1, 1), (float(U(0.3, 2)),) * 3)))
+    s.create_area_lights()
+    n_inf = 0
+    if rng.rand() < 0.55:
+        n = int(rng.randint(2, 25))
+        sky = (U(0.0, 1.0, (n, n, 3)) ** 3 * float(U(0.5, 6.0))).astype(np.float32)
+        if rng.rand() < 0.5: sky[rng.randint(n), rng.randint(n)] = U(20, 200, 3)       # a sun texel
+        s.lights.append(Light(LIGHT_IMAGE_INF, texture=s.add_texture(Texture(sky, TEX_LINEAR)), radius=100.0)); n_inf += 1
+    if rng.rand() < 0.3 or (n_inf == 0 and not s.lights):
+        s.lights.append(Light(LIGHT_UNIFORM_INF, radius=100.0, emission=tuple(U(0.1, 1.5, 3))))
+    a = U(0, 6.28); r = U(1.2, 2.2) * L; eye = (float(r * math.cos(a)), float(U(0.8, 5.0)), float(r * math.sin(a)))
+    if rng.rand() < 0.25: eye = (float(U(-1, 1)), float(U(0.5, 2.0)), float(U(-1, 1)))    # inside the scene
+    p = dict(size=(width, height), spp=spp, depth=depth, focal=float(pick(35.0, U(18, 85))),
+             fnumber=float(pick(0.0, 0.0, U(1.2, 8.0))), aperture_sides=int(pick(0, 5, 6, 8)),
+             eye=eye, target=(float(U(-1, 1)), float(U(0.3, 1.5)), float(U(-1, 1))), up=(0.0, 1.0, 0.0),
+             exposure=float(pick(0.0, U(-1, 1))), background=tuple(float(v) for v in U(0, 0.3, 3)))
+    return s, p

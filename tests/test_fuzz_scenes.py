@@ -22,13 +22,8 @@ import pytest
 from tests.conftest import ORACLE_BIN, REF_BIN
 
 REGRESSION_SEEDS = [612, 2364, 2960]
-CPU_SEEDS = list(range(6)) + REGRESSION_SEEDS
-GPU_SEEDS = list(range(40)) + REGRESSION_SEEDS
-
-
-def _size(seed):
-    """(spp, depth) of a seed: every third seed at 16 spp, every fourth at 12 bounces"""
-    return (4 if seed % 3 else 16), (6 if seed % 4 else 12)
+CPU_SEEDS = list(range(8)) + REGRESSION_SEEDS               # (4: a crowd of 70, 7: of 260 instance nodes)
+GPU_SEEDS = list(range(40)) + [100, 210] + REGRESSION_SEEDS          # (100, 210: crowds of 1000 / 4300 instance nodes)
 FUZZ_PIPELINES = {"wavefront": 0, "megakernel": 1, "wavefront+general_trace": 4, "wavefront+wide_trees": 256,
                   "wavefront+path_pool": 512}
 
@@ -42,9 +37,9 @@ def _checker():
     return exe
 
 
-def _reference_frame(tmp_path, seed, width, height, spp, depth):
+def _reference_frame(tmp_path, seed):
     from yart_amd import scenes
-    s, p = scenes.random_scene(seed, width, height, spp, depth)
+    s, p = scenes.fuzz_case(seed)
     sp, pp, ref = str(tmp_path / f"{seed}.yscn"), str(tmp_path / f"{seed}.txt"), str(tmp_path / f"{seed}.ref.f32")
     s.save(sp)
     # One worker thread: a frame of one tile and 2-3 progressive waves is over before the reference has started all its
@@ -67,7 +62,7 @@ def test_random_scene_is_deterministic():
 
 @pytest.mark.parametrize("seed", CPU_SEEDS)
 def test_random_scenes_on_host(hostsim, hostsim_lean, tmp_path, seed):
-    _, _, sp, pp, ref = _reference_frame(tmp_path, seed, 64, 48, *_size(seed))
+    _, _, sp, pp, ref = _reference_frame(tmp_path, seed)
     got = str(tmp_path / "got.f32")
     for exe in (hostsim, hostsim_lean):
         r = subprocess.run([exe, "render", sp, pp, got], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
@@ -83,7 +78,7 @@ def test_random_scenes_on_device(built, tmp_path):
     assert api.lib().yart_hip_device_count() > 0, "no HIP device: the GPU tests need the real kernels"
     bad = []
     for seed in GPU_SEEDS:
-        s, p, _, _, ref = _reference_frame(tmp_path, seed, 64, 48, *_size(seed))
+        s, p, _, _, ref = _reference_frame(tmp_path, seed)
         ds = api.DeviceScene(s, device=0)
         for name, flags in FUZZ_PIPELINES.items():
             img, _ = ds.render(p, flags=flags)

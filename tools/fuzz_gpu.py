@@ -11,7 +11,7 @@ first, last = int(sys.argv[1]), int(sys.argv[2])
 tmp = tempfile.mkdtemp()
 bad = 0; ref_hangs = 0; frames = 0; nan_frames = 0; t0 = time.time()
 for seed in range(first, last):
-    s, p = scenes.random_scene(seed, 64, 48, 4 if seed % 3 else 16, 6 if seed % 4 else 12)
+    s, p = scenes.fuzz_case(seed)
     sp, pp, rf = f"{tmp}/s.yscn", f"{tmp}/p.txt", f"{tmp}/r.f32"
     s.save(sp); scenes.write_params(pp, p, threads=1)     # (one worker: see _reference_frame's note in tests/test_fuzz_scenes.py)
     try:

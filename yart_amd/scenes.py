@@ -720,14 +720,15 @@ def stacked_leaves(width=96, height=96, spp=4, depth=4, stacks=(40, 32, 64, 31, 
     return s, p
 
 
-def random_scene(seed, width=64, height=48, spp=4, depth=6):
+def random_scene(seed, width=64, height=48, spp=4, depth=6, crowd=0):
     """Seeded random scene of the parity fuzz (tests/test_fuzz_scenes.py): every constructor argument of the reference's
     ParametricBSDF (bsdf/parametric.hpp:16-37) drawn at random — with the end points 0 and 1 over-represented, they pick other
     branches of parametric.cpp —, every texture kind at odd, non-square sizes (texture.hpp:105-161), alpha cut-outs, thin and
     refractive transmission with volume absorption, emissive triangles with and without emission textures, a triangle soup next
     to smooth shapes, instances under nested non-uniformly scaled and rotated nodes (ray-integrator.cpp:20-54), zero to two
     infinite lights, pinhole and thin-lens cameras (camera.hpp:138-164). No two seeds share a code path mix; nothing is tuned
-    to look good."""
+    to look good. crowd > 0: that many further instance nodes of small meshes under nested groups (64 nodes and more: the lean
+    kernels' other scene-graph walks — top-level hierarchy, chunked candidate masks, per-lane node walk)."""
     rng = np.random.RandomState(seed)
     s = Scene()
     U = rng.uniform
@@ -824,6 +825,24 @@ def random_scene(seed, width=64, height=48, spp=4, depth=6):
             t = U(-L * 0.5, L * 0.5, 3); t[1] = abs(t[1]) * 0.3
             s.add_node(mesh, parent, *trs(tuple(t), tuple(U(-1, 1, 3) + 1e-3), float(U(-3.1, 3.1)),
                                           pick(tuple(U(0.4, 1.8, 3)), (1, 1, 1), (float(U(0.3, 2)),) * 3)))
+    if crowd:
+        crowd_meshes = []
+        for _ in range(int(rng.randint(1, 5))):
+            bb = MeshBuilder()
+            shapes(bb, int(rng.randint(1, 3)), 0.6)
+            crowd_meshes.append(s.add_mesh(bb.build()))
+        left = int(crowd)
+        while left > 0:
+            g = s.add_node(-1, 0, *trs(tuple(U(-L, L, 3) * (1, 0.2, 1)), tuple(U(-1, 1, 3) + 1e-3), float(U(-3.1, 3.1)),
+                                       tuple(U(0.6, 1.5, 3))))
+            left -= 1
+            if rng.rand() < 0.3 and left > 0:
+                g = s.add_node(-1, g, *trs(tuple(U(-1, 1, 3)), (0, 1, 0), float(U(-3.1, 3.1)), (1, 1, 1))); left -= 1
+            for _inst in range(min(left, int(rng.randint(1, 12)))):
+                t = U(-2.0, 2.0, 3); t[1] = abs(t[1]) * 0.5
+                s.add_node(crowd_meshes[rng.randint(len(crowd_meshes))], g,
+                           *trs(tuple(t), tuple(U(-1, 1, 3) + 1e-3), float(U(-3.1, 3.1)), pick((1, 1, 1), tuple(U(0.2, 0.9, 3)))))
+                left -= 1
     s.create_area_lights()
     n_inf = 0
     if rng.rand() < 0.55:
@@ -840,3 +859,11 @@ def random_scene(seed, width=64, height=48, spp=4, depth=6):
              eye=eye, target=(float(U(-1, 1)), float(U(0.3, 1.5)), float(U(-1, 1))), up=(0.0, 1.0, 0.0),
              exposure=float(pick(0.0, U(-1, 1))), background=tuple(float(v) for v in U(0, 0.3, 3)))
     return s, p
+
+
+def fuzz_case(seed, width=64, height=48):
+    """The parity fuzz's scene + settings for a seed (tests/test_fuzz_scenes.py, tools/fuzz_gpu.py): every third seed at 16 spp,
+    every fourth at 12 bounces; some seeds with a crowd of instance nodes (70 / 260 / 1000 / 4300: the lean kernels' scene-graph
+    walks for 64 nodes and more)."""
+    crowd = 4300 if seed % 211 == 210 else 1000 if seed % 101 == 100 else 260 if seed % 13 == 7 else 70 if seed % 7 == 4 else 0
+    return random_scene(seed, width, height, 4 if seed % 3 else 16, 6 if seed % 4 else 12, crowd)

@@ -37,9 +37,12 @@ def _checker():
     return exe
 
 
-def _reference_frame(tmp_path, seed):
+FRAME_SEEDS = list(range(16))          # second family: random frame sizes, sample counts, wave schedules, tile sizes
+
+
+def _reference_frame(tmp_path, seed, frames=False):
     from yart_amd import scenes
-    s, p = scenes.fuzz_case(seed)
+    s, p = scenes.fuzz_frame_case(seed) if frames else scenes.fuzz_case(seed)
     sp, pp, ref = str(tmp_path / f"{seed}.yscn"), str(tmp_path / f"{seed}.txt"), str(tmp_path / f"{seed}.ref.f32")
     s.save(sp)
     # One worker thread: a frame of one tile and 2-3 progressive waves is over before the reference has started all its
@@ -69,6 +72,36 @@ def test_random_scenes_on_host(hostsim, hostsim_lean, tmp_path, seed):
         assert "differs" not in r.stderr, f"seed {seed}: the lean walk kept a ray the general walk treats differently\n{r.stderr[:2000]}"
         g = np.fromfile(got, np.uint32)
         assert np.array_equal(ref, g), f"seed {seed} / {os.path.basename(exe)}: {(ref != g).sum()} words differ"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/yart_ref not built here")
+@pytest.mark.parametrize("seed", FRAME_SEEDS[:8])
+def test_random_frame_settings_oracle_equals_reference(tmp_path, seed):
+    """The oracle restatement under random frame sizes / sample counts / wave schedules / tile sizes (hostsim renders one
+    wave only: it is no checker for this family)."""
+    _, _, sp, pp, ref = _reference_frame(tmp_path, seed, frames=True)
+    got = str(tmp_path / "got.f32")
+    subprocess.run([ORACLE_BIN, "render", sp, pp, got], check=True, stdout=subprocess.DEVNULL)
+    g = np.fromfile(got, np.uint32)
+    assert np.array_equal(ref, g), f"seed {seed}: {(ref != g).sum()} words differ"
+
+
+@pytest.mark.gpu
+def test_random_frame_settings_on_device(built, tmp_path):
+    from yart_amd import api
+    from tests.test_gpu_parity import PIPELINE_FLAGS
+    bad = []
+    for seed in FRAME_SEEDS:
+        s, p, _, _, ref = _reference_frame(tmp_path, seed, frames=True)
+        ds = api.DeviceScene(s, device=0)
+        for name, flags in PIPELINE_FLAGS.items():
+            img, _ = ds.render(p, flags=flags)
+            g = np.ascontiguousarray(img, np.float32).view(np.uint32).ravel()
+            if not np.array_equal(ref, g):
+                bad.append(f"seed {seed} / {name} / {p['size']} spp {p['spp']} waves {p['first_wave']}..{p['max_wave']} tile {p['tile']}: "
+                           f"{(ref != g).sum()} of {ref.size} words differ")
+        ds.close()
+    assert not bad, "\n".join(bad)
 
 
 @pytest.mark.gpu

@@ -1,5 +1,6 @@
 """GPU-box experiment: tests/test_fuzz_scenes.py's comparison over a wider range of seeds (FIRST LAST), every pipeline variant of
-tests/test_gpu_parity.py::PIPELINE_FLAGS, against the compiled reference (oracle/_ref/yart_ref). Prints one line per mismatch."""
+tests/test_gpu_parity.py::PIPELINE_FLAGS, against the compiled reference (oracle/_ref/yart_ref). Prints one line per mismatch. CROWD_ONLY=1: only the seeds with 64 nodes and more. FRAMES=1: the second family
+(scenes.fuzz_frame_case: random frame sizes, sample counts, wave schedules, tile sizes)."""
 import faulthandler, os, subprocess, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +12,9 @@ first, last = int(sys.argv[1]), int(sys.argv[2])
 tmp = tempfile.mkdtemp()
 bad = 0; ref_hangs = 0; frames = 0; nan_frames = 0; t0 = time.time()
 for seed in range(first, last):
-    s, p = scenes.fuzz_case(seed)
+    if os.environ.get("CROWD_ONLY") and not (seed % 7 == 4 or seed % 13 == 7 or seed % 101 == 100 or seed % 211 == 210):
+        continue                                   # (only the seeds scenes.fuzz_case gives a crowd of instance nodes)
+    s, p = scenes.fuzz_frame_case(seed) if os.environ.get("FRAMES") else scenes.fuzz_case(seed)
     sp, pp, rf = f"{tmp}/s.yscn", f"{tmp}/p.txt", f"{tmp}/r.f32"
     s.save(sp); scenes.write_params(pp, p, threads=1)     # (one worker: see _reference_frame's note in tests/test_fuzz_scenes.py)
     try:

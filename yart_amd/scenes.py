@@ -586,6 +586,8 @@ def write_params(path, p, threads=None, probe_pixels=None, **override):
     q = dict(p); q.update(override)
     lines = []
     for key, val in q.items():
+        if key in ("max_batch_paths", "pool_paths"):       # this library's own knobs (YartRenderParams), not the reference's
+            continue
         if isinstance(val, (tuple, list, np.ndarray)):
             lines.append(f"{key} " + " ".join(repr(float(v)) if key != "size" else str(int(v)) for v in val))
         elif isinstance(val, float):
@@ -867,3 +869,19 @@ def fuzz_case(seed, width=64, height=48):
     walks for 64 nodes and more)."""
     crowd = 4300 if seed % 211 == 210 else 1000 if seed % 101 == 100 else 260 if seed % 13 == 7 else 70 if seed % 7 == 4 else 0
     return random_scene(seed, width, height, 4 if seed % 3 else 16, 6 if seed % 4 else 12, crowd)
+
+
+def fuzz_frame_case(seed):
+    """Second family of the parity fuzz: random_scene(seed) under random FRAME settings — sizes from 1x1 up, across the tile
+    boundary, sample counts that are no powers of two (the sampler rounds log2(spp): sampler.hpp:84-100), progressive wave
+    schedules (tile-renderer.hpp:121-124, 284-289), other tile sizes (the sampler's Morton index depends on it)."""
+    rng = np.random.RandomState(seed ^ 0x5EED)
+    pick = lambda *v: v[rng.randint(len(v))]
+    w, h = int(rng.randint(1, 150)), int(rng.randint(1, 100))
+    spp = int(pick(1, 2, 3, 4, 5, 7, 8, 12, 16, 24, 33, 64))
+    s, p = random_scene(seed, w, h, spp, int(pick(1, 2, 3, 5, 8, 16)))
+    p["first_wave"] = int(pick(spp, spp, 1, 2, 4)); p["max_wave"] = int(pick(spp, spp, 2, 4, 8, 16))
+    p["tile"] = int(pick(64, 64, 64, 32, 16, 128))
+    # device-side only (the reference has no such notion; write_params drops them): small batches, small path pools
+    p["max_batch_paths"] = int(pick(0, 0, 257, 1000, 5000)); p["pool_paths"] = int(pick(0, 64, 640, 4096))
+    return s, p

@@ -122,13 +122,15 @@ static int doKat(Ctx& c, const params::Params& p, const std::string& outPath) {
   {
     std::vector<float> fo, ro6;
     std::vector<int64_t> io;
+    // the reference's probe integrator holds ONE sampler, constructed and never started on a pixel (ref_driver.cpp: pixel 0,
+    // sample 0, dimension 0): stochastic alpha tests of the probe rays draw from it one after the other
+    Sampler dummy; dummy.dim = 0; dummy.morton = 0; dummy.pix = 0;
     for (size_t i = 0; i + 1 < p.probePixels.size(); i += 2) {
       f3 o, d;
       cameraRay(c.cam, p.probePixels[i], p.probePixels[i + 1], mk2(0.5f, 0.5f), mk2(0.5f, 0.5f), o, d);
       ro6.push_back(o.x); ro6.push_back(o.y); ro6.push_back(o.z); ro6.push_back(d.x); ro6.push_back(d.y); ro6.push_back(d.z);
       HitRec hr; hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
       f3 att = mk3(1.0f);
-      Sampler dummy; dummy.dim = 0; dummy.morton = 0;
       AlphaCtx ac; ac.sampler = &dummy; ac.cfg = c.rc.sampler;
       bool hit = traverseScene<false>(c.sc, o, d, 0.001f, hr, att, px.stk, ac);
       io.push_back(hit);

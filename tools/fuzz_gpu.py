@@ -14,9 +14,13 @@ bad = 0; ref_hangs = 0; frames = 0; nan_frames = 0; t0 = time.time()
 for seed in range(first, last):
     if os.environ.get("CROWD_ONLY") and not (seed % 7 == 4 or seed % 13 == 7 or seed % 101 == 100 or seed % 211 == 210):
         continue                                   # (only the seeds scenes.fuzz_case gives a crowd of instance nodes)
-    s, p = scenes.fuzz_frame_case(seed) if os.environ.get("FRAMES") else scenes.fuzz_case(seed)
+    if os.environ.get("SIZE"):                      # SIZE=WxH: the first family at a larger frame (many tiles: the reference's default workers)
+        w, h = (int(v) for v in os.environ["SIZE"].split("x"))
+        s, p = scenes.fuzz_case(seed, w, h)
+    else:
+        s, p = scenes.fuzz_frame_case(seed) if os.environ.get("FRAMES") else scenes.fuzz_case(seed)
     sp, pp, rf = f"{tmp}/s.yscn", f"{tmp}/p.txt", f"{tmp}/r.f32"
-    s.save(sp); scenes.write_params(pp, p, threads=1)     # (one worker: see _reference_frame's note in tests/test_fuzz_scenes.py)
+    s.save(sp); scenes.write_params(pp, p, threads=None if os.environ.get("SIZE") else 1)     # (one worker: see _reference_frame's note in tests/test_fuzz_scenes.py)
     try:
         subprocess.run([REF, "render", sp, pp, rf], check=True, stdout=subprocess.DEVNULL, timeout=120)
     except subprocess.TimeoutExpired:
@@ -36,6 +40,6 @@ for seed in range(first, last):
             bad += 1
             print(f"MISMATCH seed {seed} / {name}: {(ref != g).sum()} of {ref.size} words differ", flush=True)
     ds.close()
-    if seed % 25 == 0: print(f"seed {seed} done, {time.time() - t0:.0f} s", flush=True)
+    if seed % (1 if os.environ.get('SIZE') else 25) == 0: print(f"seed {seed} done, {time.time() - t0:.0f} s", flush=True)
 print(f"seeds {first}..{last - 1}: {frames} frames of {len(PIPELINE_FLAGS)} pipelines, {bad} differ from the reference's; "
       f"{nan_frames} reference frames hold a NaN; the reference itself hung on {ref_hangs} seeds")

@@ -1,5 +1,6 @@
 """GPU-box experiment: tests/test_fuzz_scenes.py's comparison over a wider range of seeds (FIRST LAST), every pipeline variant of
-tests/test_gpu_parity.py::PIPELINE_FLAGS, against the compiled reference (oracle/_ref/yart_ref). Prints one line per mismatch. CROWD_ONLY=1: only the seeds with 64 nodes and more. FRAMES=1: the second family
+tests/test_gpu_parity.py::PIPELINE_FLAGS, against the compiled reference (oracle/_ref/yart_ref). Prints one line per mismatch. CROWD_ONLY=1: only the seeds with 64 nodes and more. EXTRAS_ONLY=1: only the seeds with
+random_scene's extras. FRAMES=1: the second family
 (scenes.fuzz_frame_case: random frame sizes, sample counts, wave schedules, tile sizes)."""
 import faulthandler, os, subprocess, sys, tempfile, time
 import numpy as np
@@ -14,6 +15,8 @@ bad = 0; ref_hangs = 0; frames = 0; nan_frames = 0; t0 = time.time()
 for seed in range(first, last):
     if os.environ.get("CROWD_ONLY") and not (seed % 7 == 4 or seed % 13 == 7 or seed % 101 == 100 or seed % 211 == 210):
         continue                                   # (only the seeds scenes.fuzz_case gives a crowd of instance nodes)
+    if os.environ.get("EXTRAS_ONLY") and seed % 9 != 5:
+        continue                                   # (only the seeds with coincident duplicates, degenerate triangles, extreme scales)
     if os.environ.get("SIZE"):                      # SIZE=WxH: the first family at a larger frame (many tiles: the reference's default workers)
         w, h = (int(v) for v in os.environ["SIZE"].split("x"))
         s, p = scenes.fuzz_case(seed, w, h)

@@ -722,7 +722,7 @@ def stacked_leaves(width=96, height=96, spp=4, depth=4, stacks=(40, 32, 64, 31, 
     return s, p
 
 
-def random_scene(seed, width=64, height=48, spp=4, depth=6, crowd=0):
+def random_scene(seed, width=64, height=48, spp=4, depth=6, crowd=0, extras=False):
     """Seeded random scene of the parity fuzz (tests/test_fuzz_scenes.py): every constructor argument of the reference's
     ParametricBSDF (bsdf/parametric.hpp:16-37) drawn at random — with the end points 0 and 1 over-represented, they pick other
     branches of parametric.cpp —, every texture kind at odd, non-square sizes (texture.hpp:105-161), alpha cut-outs, thin and
@@ -730,7 +730,10 @@ def random_scene(seed, width=64, height=48, spp=4, depth=6, crowd=0):
     to smooth shapes, instances under nested non-uniformly scaled and rotated nodes (ray-integrator.cpp:20-54), zero to two
     infinite lights, pinhole and thin-lens cameras (camera.hpp:138-164). No two seeds share a code path mix; nothing is tuned
     to look good. crowd > 0: that many further instance nodes of small meshes under nested groups (64 nodes and more: the lean
-    kernels' other scene-graph walks — top-level hierarchy, chunked candidate masks, per-lane node walk)."""
+    kernels' other scene-graph walks — top-level hierarchy, chunked candidate masks, per-lane node walk). extras: geometry that
+    makes ORDER matter — coincident duplicates with different materials (equal-t candidates, also cut-outs on top of opaque
+    twins), zero-area and needle triangles, planes at exactly 0 — and instances at extreme scales (1e-3 .. 1e3: the padded world
+    boxes and intervals of the conservative culls)."""
     rng = np.random.RandomState(seed)
     s = Scene()
     U = rng.uniform
@@ -827,6 +830,29 @@ def random_scene(seed, width=64, height=48, spp=4, depth=6, crowd=0):
             t = U(-L * 0.5, L * 0.5, 3); t[1] = abs(t[1]) * 0.3
             s.add_node(mesh, parent, *trs(tuple(t), tuple(U(-1, 1, 3) + 1e-3), float(U(-3.1, 3.1)),
                                           pick(tuple(U(0.4, 1.8, 3)), (1, 1, 1), (float(U(0.3, 2)),) * 3)))
+    if extras:
+        be = MeshBuilder()
+        for _ in range(int(rng.randint(1, 5))):        # coincident twins / triplets: same vertices, other materials, rotated vertex order
+            c = U(-2, 2, 3); c[1] = abs(c[1]) + 0.1
+            a = U(0, 6.28); t = np.array([math.cos(a), 0.0, math.sin(a)]) * U(0.4, 1.5); up = np.array([0.0, U(0.5, 1.8), 0.0])
+            q = [c - t, c + t, c + t + up, c - t + up]
+            for k in range(int(rng.randint(2, 4))):
+                r = int(rng.randint(4)) if k else 0
+                be.quad(*[tuple(q[(i + r) % 4]) for i in range(4)], M(), uv_scale=float(U(0.5, 2)))
+        # a slab whose faces lie at exactly x = 0 / y = 0 / z = 0, zero-area triangles, needles
+        be.box((0.0, 0.0, 0.0), (float(U(0.3, 1.5)), float(U(0.3, 1.5)), float(U(0.3, 1.5))), M())
+        k = int(rng.randint(2, 8))
+        pz = U(-1.5, 1.5, (k, 3, 3)); pz[:, 2] = pz[:, 1]                                    # two equal vertices
+        pn = U(-1.5, 1.5, (k, 3, 3)); pn[:, 2] = pn[:, 1] + U(-1e-6, 1e-6, (k, 3))           # needles
+        pp_ = np.concatenate([pz, pn]).reshape(-1, 3)
+        nn = U(-1, 1, (len(pp_), 3)); nn /= np.linalg.norm(nn, axis=-1, keepdims=True)
+        be.add(pp_, nn, None, U(0, 1, (len(pp_), 2)), np.arange(len(pp_)).reshape(-1, 3), M())
+        em = s.add_mesh(be.build())
+        s.add_node(em, 0, *trs(tuple(U(-1, 1, 3) * (1, 0, 1)), (0, 1, 0), float(pick(0.0, U(-3, 3))), (1, 1, 1)))
+        # the same mesh at extreme scales (their inverse transforms scale the ray the other way)
+        for sc_ in (1e-3, 1e3, float(10 ** U(-2.5, 2.5))):
+            g = s.add_node(-1, 0, *trs(tuple(U(-3, 3, 3) * (1, 0.1, 1)), tuple(U(-1, 1, 3) + 1e-3), float(U(-3.1, 3.1)), (sc_,) * 3))
+            s.add_node(em, g, *trs(tuple(U(-1, 1, 3) * (1, 0, 1)), (0, 1, 0), 0.0, (1 / sc_,) * 3 if rng.rand() < 0.5 else (1, 1, 1)))
     if crowd:
         crowd_meshes = []
         for _ in range(int(rng.randint(1, 5))):
@@ -866,9 +892,9 @@ def random_scene(seed, width=64, height=48, spp=4, depth=6, crowd=0):
 def fuzz_case(seed, width=64, height=48):
     """The parity fuzz's scene + settings for a seed (tests/test_fuzz_scenes.py, tools/fuzz_gpu.py): every third seed at 16 spp,
     every fourth at 12 bounces; some seeds with a crowd of instance nodes (70 / 260 / 1000 / 4300: the lean kernels' scene-graph
-    walks for 64 nodes and more)."""
+    walks for 64 nodes and more), every ninth with random_scene's `extras` (coincident duplicates, degenerate triangles, extreme scales)."""
     crowd = 4300 if seed % 211 == 210 else 1000 if seed % 101 == 100 else 260 if seed % 13 == 7 else 70 if seed % 7 == 4 else 0
-    return random_scene(seed, width, height, 4 if seed % 3 else 16, 6 if seed % 4 else 12, crowd)
+    return random_scene(seed, width, height, 4 if seed % 3 else 16, 6 if seed % 4 else 12, crowd, extras=seed % 9 == 5)
 
 
 def fuzz_frame_case(seed):

@@ -124,8 +124,26 @@ def test_random_frame_settings_on_device(built, tmp_path):
             if not np.array_equal(ref, g):
                 bad.append(f"seed {seed} / {name} / {p['size']} spp {p['spp']} waves {p['first_wave']}..{p['max_wave']} tile {p['tile']}: "
                            f"{(ref != g).sum()} of {ref.size} words differ")
+        # the same frame from its parts: ranks of a sharded render (disjoint pixel blocks, summed), and an accumulation that is
+        # handed back after the first progressive wave and resumed (YartRenderParams.start_sample / stop_sample)
+        rng = np.random.RandomState(seed + 4242)
+        world, shard = int(rng.choice([2, 3, 5, 8])), int(rng.choice([0, 8, 16]))
+        parts = [ds.render(dict(p, shard_tile=shard), rank=r, world_size=world)[0] for r in range(world)]
+        if not np.array_equal(np.ascontiguousarray(sum(parts), np.float32).view(np.uint32).ravel(), ref):
+            bad.append(f"seed {seed}: the sum of {world} ranks (shard_tile {shard}) is not the frame")
+        first = _first_wave(p)
+        if first < p["spp"]:
+            head, _ = ds.render(dict(p, stop_sample=first))
+            whole, _ = ds.render(dict(p, start_sample=first), accumulated=head)
+            if not np.array_equal(np.ascontiguousarray(whole, np.float32).view(np.uint32).ravel(), ref):
+                bad.append(f"seed {seed}: resumed after {first} of {p['spp']} samples, the frame differs")
         ds.close()
     assert not bad, "\n".join(bad)
+
+
+def _first_wave(p):
+    """samples of the first progressive wave (tile-renderer.hpp:121-124)"""
+    return min(int(p.get("first_wave", p["spp"])), int(p["spp"]))
 
 
 @pytest.mark.gpu

@@ -70,3 +70,40 @@ def test_device_tonemap_vs_reference_golden(built, look, tag):
         assert np.nanmax(err) <= 2e-5
     else:
         assert np.array_equal(ldr, hdr)
+
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "yart_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/yart_ref not built here")
+@pytest.mark.parametrize("seed", range(6))
+def test_tonemap_random_frames_vs_reference(hostsim, tmp_path, seed):
+    """Random HDR frames — 11 decades of magnitude, zeros, denormals, negative values, infinities and NaNs (a rendered frame holds
+    none of the last three: GMoN drops such samples) — through the compiled reference, the device headers on the host and the
+    oracle: the 8-bit output is the same byte for byte and every float is the same bit for bit, except that a NaN may be another
+    NaN (negative inputs of the look "none": the NaN the reference's log2 makes of them keeps its sign through min / max there)."""
+    rng = np.random.RandomState(seed)
+    x = np.exp(rng.uniform(-14, 12, (H, W, 4))).astype(np.float32)
+    m = rng.rand(H, W, 4)
+    x[m < 0.03] = 0.0
+    x[(m >= 0.03) & (m < 0.05)] *= -1
+    if seed % 2 == 0:
+        x[(m >= 0.05) & (m < 0.055)] = np.inf
+        x[(m >= 0.055) & (m < 0.06)] = np.nan
+    if seed % 3 == 1:
+        x[m > 0.9] = np.float32(1e-42)
+    x[..., 3] = 1.0
+    src = str(tmp_path / "in.f32")
+    x.tofile(src)
+    for look in ("none", "golden", "punchy", "-"):
+        outs = {}
+        for name, exe in (("ref", REF_BIN), ("device headers", hostsim), ("oracle", ORACLE)):
+            f32, ppm = str(tmp_path / "o.f32"), str(tmp_path / "o.ppm")
+            subprocess.run([exe, "tonemap", src, str(W), str(H), look, f32, ppm], check=True, capture_output=True)
+            outs[name] = (open(ppm, "rb").read(), np.fromfile(f32, np.float32) if look != "-" else None)
+        for name in ("device headers", "oracle"):
+            assert outs[name][0] == outs["ref"][0], (seed, look, name, "8-bit output differs")
+            if look != "-":
+                a, b = outs[name][1], outs["ref"][1]
+                differ = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
+                assert not differ.any(), (seed, look, name, int(differ.sum()))

@@ -107,3 +107,31 @@ def test_tonemap_random_frames_vs_reference(hostsim, tmp_path, seed):
                 a, b = outs[name][1], outs["ref"][1]
                 differ = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
                 assert not differ.any(), (seed, look, name, int(differ.sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_device_tonemap_random_frames_vs_reference(built, tmp_path, seed):
+    """k_tonemap_agx + k_encode_rgb8 on random HDR frames (as above, without the non-finite and negative values a frame cannot
+    hold) against the compiled reference run on the GPU box: floats bit for bit, bytes equal."""
+    from yart_amd import api
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/yart_ref is missing: the GPU tonemap fuzz compares against it")
+    rng = np.random.RandomState(100 + seed)
+    x = np.exp(rng.uniform(-14, 12, (H, W, 4))).astype(np.float32)
+    m = rng.rand(H, W, 4)
+    x[m < 0.03] = 0.0
+    if seed % 2:
+        x[m > 0.9] = np.float32(1e-42)
+    x[..., 3] = 1.0
+    src = str(tmp_path / "in.f32")
+    x.tofile(src)
+    for look in ("none", "golden", "punchy"):
+        f32, ppm = str(tmp_path / "o.f32"), str(tmp_path / "o.ppm")
+        subprocess.run([REF_BIN, "tonemap", src, str(W), str(H), look, f32, ppm], check=True, capture_output=True)
+        ref = np.fromfile(f32, np.float32).reshape(H, W, 4)
+        ldr, rgb = api.tonemap(x, look)
+        same = (ldr.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(ldr) & np.isnan(ref))
+        print(f"seed {seed} look {look}: identical floats {same.mean():.6f}, bytes differing {int((rgb != _ppm_bytes(ppm)).sum())}")
+        assert same.all(), (seed, look, int((~same).sum()))
+        assert np.array_equal(rgb, _ppm_bytes(ppm))

@@ -35,6 +35,40 @@ def test_estimator_functions_equal_reference_classes(hostsim, tmp_path, spp, kin
     assert same_bits_or_both_nan(got, want), np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
 
 
+REF_BIN = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "yart_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/yart_ref not built here")
+@pytest.mark.parametrize("seed", range(12))
+def test_estimator_functions_on_random_sample_groups(hostsim, tmp_path, seed):
+    """Random sample groups (24 pixels x spp x rgb: 6 decades, zeros, fireflies, every third seed with NaN / negative / infinite
+    samples, all-equal and all-zero groups) through the reference's own classes and csrc/estimator.hpp on the host, all four
+    estimators (1200 such cases run once: all equal)."""
+    rng = np.random.RandomState(seed)
+    spp = int(rng.choice([1, 2, 3, 5, 6, 7, 9, 14, 15, 16, 17, 24, 25, 26, 33, 35, 64, 100, 155, 156, 256, 300]))
+    x = np.exp(rng.uniform(-8, 6, (24, spp, 3))).astype(np.float32)
+    m = rng.rand(24, spp, 3)
+    x[m < 0.05] = 0
+    x[(m > 0.05) & (m < 0.08)] *= np.float32(1e4)
+    if seed % 3 == 0:
+        x[(m > 0.10) & (m < 0.12)] = np.nan
+        x[(m > 0.12) & (m < 0.14)] *= -1
+        x[(m > 0.14) & (m < 0.15)] = np.inf
+    if seed % 7 == 3:
+        x[:] = x[:, :1]
+    if seed % 11 == 5:
+        x[:] = 0
+    inp = os.path.join(tmp_path, "in.f32")
+    x.tofile(inp)
+    for kind in KINDS.values():
+        outs = []
+        for exe in (REF_BIN, hostsim):
+            out = os.path.join(tmp_path, "o.f32")
+            subprocess.run([exe, "estimator", str(kind), str(spp), inp, out], check=True)
+            outs.append(np.fromfile(out, np.float32))
+        assert outs[0].shape == outs[1].shape and same_bits_or_both_nan(outs[1], outs[0]), (seed, spp, kind)
+
+
 def test_bad_estimator_is_rejected(built):
     from yart_amd import api
     L = api.lib()

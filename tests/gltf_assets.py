@@ -526,3 +526,61 @@ def jpeg_encode_progressive(pixels, sampling=((1, 1), (1, 1), (1, 1)), quant=(8,
         out += bw.out
     out += b"\xFF\xD9"
     return bytes(out)
+
+
+def random_image(seed, ref_writejpg=None):
+    """A random PNG (even seeds) or JPEG (odd seeds) for the decoder fuzz (tests/test_gltf_import.py): PNG colour types 0 / 2 / 3 /
+    4 / 6 at every legal depth, sizes 1..40, random filters, Adam7, split IDAT, palettes with tRNS, colour keys; JPEG sizes 1..69,
+    1 or 3 components, ten sampling layouts, random quantisation steps, restart intervals, one scan per component, fill bytes,
+    JFIF / Adobe markers, progressive files — and, if ref_writejpg(png_bytes, quality) -> jpeg_bytes is given, files written by the
+    reference's own encoder (stb_image_write). Returns (bytes, "png" | "jpg", description)."""
+    rng = np.random.default_rng(seed)
+    if seed % 2 == 0:
+        ct = int(rng.choice([0, 2, 3, 4, 6]))
+        depth = int(rng.choice({0: [1, 2, 4, 8, 16], 2: [8, 16], 3: [1, 2, 4, 8], 4: [8, 16], 6: [8, 16]}[ct]))
+        h, w = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+        ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ct]
+        kw = {}
+        if ct == 3:
+            npal = int(rng.integers(1, (1 << depth) + 1))
+            kw["palette"] = rng.integers(0, 256, (npal, 3))
+            pix = rng.integers(0, npal, (h, w, 1))
+            if rng.random() < 0.5:
+                kw["trns"] = bytes(rng.integers(0, 256, int(rng.integers(1, npal + 1))).astype(np.uint8))
+        else:
+            pix = rng.integers(0, 1 << depth, (h, w, ch))
+            if rng.random() < 0.4:
+                pix = (np.add.outer(np.arange(h) * 7, np.arange(w) * 3)[..., None] * np.ones(ch, int)) % (1 << depth)
+            if ct in (0, 2) and rng.random() < 0.4:
+                key = pix[int(rng.integers(h)), int(rng.integers(w))]
+                kw["trns"] = b"".join(struct.pack(">H", int(v)) for v in key)
+        fl = tuple(int(v) for v in rng.choice([0, 1, 2, 3, 4], int(rng.integers(1, 6))))
+        data = png_encode(pix, ct, depth=depth, filters=fl, interlace=bool(rng.random() < 0.4),
+                          idat_split=int(rng.choice([0, 0, 7, 50, 1000])), **kw)
+        return data, "png", f"png type {ct} depth {depth} {w}x{h} {sorted(kw)} filters {fl}"
+    h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    nc = int(rng.choice([1, 3, 3, 3]))
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 70 * np.sin(xx / rng.uniform(2, 9)) + 40 * np.cos(yy / rng.uniform(2, 9)),
+                    128 + 60 * np.sin((xx + yy) / rng.uniform(3, 9)), 128 + 80 * np.cos(xx / 4.0 - yy / 6.0)], -1)
+    img = img + rng.normal(0, rng.uniform(0, 40), (h, w, 3))
+    if rng.random() < 0.2:
+        img = rng.integers(0, 256, (h, w, 3)).astype(float)
+    img = np.clip(img, 0, 255).astype(np.uint8)[..., :nc]
+    layouts = [((1, 1), (1, 1), (1, 1)), ((2, 2), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((1, 2), (1, 1), (1, 1)),
+               ((4, 1), (1, 1), (1, 1)), ((1, 4), (1, 2), (1, 1)), ((2, 2), (2, 1), (1, 1)), ((2, 1), (1, 1), (2, 1)),
+               ((4, 2), (1, 1), (1, 1)), ((2, 2), (1, 2), (1, 2))]
+    samp = layouts[int(rng.integers(len(layouts)))] if nc == 3 else (((1, 1),), ((2, 2),), ((2, 1),))[int(rng.integers(3))]
+    q = (int(rng.integers(1, 40)), int(rng.integers(1, 60)))
+    rst = int(rng.choice([0, 0, 1, 2, 3, 7]))
+    mode = int(rng.integers(3))
+    if mode == 0 and nc == 3 and rng.random() < 0.5 and ref_writejpg is not None:
+        quality = int(rng.integers(1, 101))
+        return ref_writejpg(png_encode(img, 2), quality), "jpg", f"jpg by stb_image_write q{quality} {w}x{h}"
+    if mode < 2:
+        kw = dict(sampling=samp, quant=q, restart=rst, interleaved=bool(rng.random() < 0.7), fill_bytes=bool(rng.random() < 0.3))
+        if nc == 3 and rng.random() < 0.3:
+            kw.update(jfif=bool(rng.random() < 0.5), adobe_transform=int(rng.choice([0, 1])))
+        return jpeg_encode(img, **kw), "jpg", f"jpg baseline {w}x{h} x{nc} {kw}"
+    return (jpeg_encode_progressive(img, sampling=samp, quant=q, restart=rst), "jpg",
+            f"jpg progressive {w}x{h} x{nc} {samp} q{q} restart {rst}")

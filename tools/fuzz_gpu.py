@@ -2,7 +2,7 @@
 tests/test_gpu_parity.py::PIPELINE_FLAGS, against the compiled reference (oracle/_ref/yart_ref). Prints one line per mismatch. CROWD_ONLY=1: only the seeds with 64 nodes and more. EXTRAS_ONLY=1: only the seeds with
 random_scene's extras. COMBOS=1: random combinations of the pipeline flags. FRAMES=1: the second family
 (scenes.fuzz_frame_case: random frame sizes, sample counts, wave schedules, tile sizes)."""
-import faulthandler, os, subprocess, sys, tempfile, time
+import faulthandler, json, os, subprocess, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,7 +11,7 @@ from tests.test_gpu_parity import PIPELINE_FLAGS
 REF = os.path.join(ROOT, "oracle", "_ref", "yart_ref")
 first, last = int(sys.argv[1]), int(sys.argv[2])
 tmp = tempfile.mkdtemp()
-bad = 0; ref_hangs = 0; frames = 0; nan_frames = 0; t0 = time.time()
+bad = 0; bad_rays = 0; ref_hangs = 0; frames = 0; nan_frames = 0; t0 = time.time()
 for seed in range(first, last):
     if os.environ.get("CROWD_ONLY") and not (seed % 7 == 4 or seed % 13 == 7 or seed % 101 == 100 or seed % 211 == 210):
         continue                                   # (only the seeds scenes.fuzz_case gives a crowd of instance nodes)
@@ -25,7 +25,8 @@ for seed in range(first, last):
     sp, pp, rf = f"{tmp}/s.yscn", f"{tmp}/p.txt", f"{tmp}/r.f32"
     s.save(sp); scenes.write_params(pp, p, threads=None if os.environ.get("SIZE") else 1)     # (one worker: see _reference_frame's note in tests/test_fuzz_scenes.py)
     try:
-        subprocess.run([REF, "render", sp, pp, rf], check=True, stdout=subprocess.DEVNULL, timeout=120)
+        out = subprocess.run([REF, "render", sp, pp, rf], check=True, capture_output=True, text=True, timeout=120).stdout
+        ref_rays = int(json.loads(out.strip().splitlines()[-1])["rays"])
     except subprocess.TimeoutExpired:
         print(f"seed {seed}: the REFERENCE did not finish within 120 s (skipped)", flush=True); ref_hangs += 1
         continue
@@ -45,8 +46,11 @@ for seed in range(first, last):
     for name, flags in pipelines.items():
         faulthandler.dump_traceback_later(90, exit=True)       # a render that does not return: say where, and stop
         print(f"seed {seed} {name}", file=open(os.path.join(tmp, "last"), "w"))
-        img, _ = ds.render(p, flags=flags)
+        img, st = ds.render(p, flags=flags)
         faulthandler.cancel_dump_traceback_later()
+        if int(st["rays"]) != ref_rays:             # the reference's ray count (RenderData::totalRays): an integer result
+            bad_rays += 1
+            print(f"RAYS seed {seed} / {name}: {st['rays']} rays, the reference counts {ref_rays}", flush=True)
         g = np.ascontiguousarray(img, np.float32).view(np.uint32).ravel()
         frames += 1
         if not np.array_equal(ref, g):
@@ -55,4 +59,4 @@ for seed in range(first, last):
     ds.close()
     if seed % (1 if os.environ.get('SIZE') else 25) == 0: print(f"seed {seed} done, {time.time() - t0:.0f} s", flush=True)
 print(f"seeds {first}..{last - 1}: {frames} frames of {len(PIPELINE_FLAGS)} pipelines, {bad} differ from the reference's; "
-      f"{nan_frames} reference frames hold a NaN; the reference itself hung on {ref_hangs} seeds")
+      f"{bad_rays} ray counts differ; {nan_frames} reference frames hold a NaN; the reference itself hung on {ref_hangs} seeds")

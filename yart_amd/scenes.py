@@ -586,7 +586,7 @@ def write_params(path, p, threads=None, probe_pixels=None, **override):
     q = dict(p); q.update(override)
     lines = []
     for key, val in q.items():
-        if key in ("max_batch_paths", "pool_paths"):       # this library's own knobs (YartRenderParams), not the reference's
+        if key in ("max_batch_paths", "pool_paths") or key.startswith("_"):   # this library's own knobs (YartRenderParams) / test notes
             continue
         if isinstance(val, (tuple, list, np.ndarray)):
             lines.append(f"{key} " + " ".join(repr(float(v)) if key != "size" else str(int(v)) for v in val))

@@ -224,6 +224,12 @@ static int doRender(const std::string& scenePath, const std::string& paramPath,
   }
   r.backgroundColor = float3(p.background[0], p.background[1], p.background[2]);
 
+  // The ray count reported is the sum of the per-tile counts the renderer hands its tile callback (called under the buffer lock, one
+  // tile at a time). RenderData::totalRays is the same sum added up WITHOUT the lock (tile-renderer.hpp:217-218: two plain `+=` of
+  // a uint64_t from every worker): with several workers it comes out short now and then — exactly one 64x64 tile's rays missing in
+  // 10 of 60 full-HD renders on a 256-thread host. Printed next to it as total_rays_unsynchronised.
+  uint64_t tileRaySum = 0;
+  r.onRenderTileComplete = [&](Renderer::RenderData, Renderer::TileData t) { tileRaySum += t.rays; };
   auto t0 = std::chrono::high_resolution_clock::now();
   auto d = r.renderSync();
   auto t1 = std::chrono::high_resolution_clock::now();
@@ -239,8 +245,8 @@ static int doRender(const std::string& scenePath, const std::string& paramPath,
   std::fclose(f);
 
   double msamples = double(p.width) * p.height * p.spp / sec * 1e-6;
-  std::printf("{\"rays\": %llu, \"seconds\": %.6f, \"msamples_per_s\": %.6f, \"threads\": %u}\n",
-              (unsigned long long) d.totalRays, sec, msamples, r.threadCount);
+  std::printf("{\"rays\": %llu, \"total_rays_unsynchronised\": %llu, \"seconds\": %.6f, \"msamples_per_s\": %.6f, \"threads\": %u}\n",
+              (unsigned long long) tileRaySum, (unsigned long long) d.totalRays, sec, msamples, r.threadCount);
   return 0;
 }
 

@@ -413,3 +413,33 @@ def test_bench_inproc_mode_rehearsal(api):
     pb = list(st["paths_at_bounce"])
     assert pb[0] == 96 * 54 * 4 and all(pb[i] >= pb[i + 1] for i in range(4)) and pb[1] > 0 and pb[5] == 0
     scene.close()
+
+
+def test_concurrent_callers(api):
+    """The C ABI is thread-safe per handle (include/yart_hip.h): host threads that render through ONE scene handle at the same time are
+    serialised by the handle and each gets its own frame; threads on DIFFERENT handles of the same device run side by side. Every
+    frame equals the one the same call returns alone."""
+    import threading
+    from yart_amd import scenes
+    sa, pa = scenes.fuzz_case(3)
+    sb, pb = scenes.fuzz_case(14)
+    A, B = api.DeviceScene(sa, device=0), api.DeviceScene(sb, device=0)
+    jobs = [(A, dict(pa, spp=4), 0), (A, dict(pa, spp=8), 512), (A, dict(pa, spp=16), 256), (B, dict(pb, spp=4), 0),
+            (B, dict(pb, spp=8), 1), (A, dict(pa, spp=4), 4), (B, dict(pb, spp=16), 16), (A, dict(pa, spp=8), 0)]
+    alone = [ds.render(p, flags=f)[0].copy() for ds, p, f in jobs]
+    got, errors = [None] * len(jobs), []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                ds, p, f = jobs[k]
+                got[k] = ds.render(p, flags=f)[0].copy()
+        except Exception as e:          # noqa: BLE001 (reported below, from the main thread)
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    for k in range(len(jobs)):
+        assert np.array_equal(got[k].view(np.uint32), alone[k].view(np.uint32)), k
+    A.close(); B.close()

@@ -527,7 +527,7 @@ static int sceneWide(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& hit, bo
 }
 
 static int doWideCheck(Ctx& c, const params::Params& p, uint32_t W, uint32_t H, uint32_t fan) {
-  if (!c.im.wideOk) { std::fprintf(stderr, "widecheck: the scene has no 8-wide trees\n"); return 3; }
+  if (!c.im.wideOk) { std::fprintf(stderr, "widecheck: the scene has no 8-wide trees (deepest stack a tree would need: %u)\n", c.im.wideMaxStack); return 3; }
   const SceneDev& sc = c.sc;
   std::vector<uint64_t> stack(kRefStackDepth);
   TravStack stk; stk.lds = stack.data(); stk.ldsStride = 1; stk.ldsDepth = kRefStackDepth; stk.spill = nullptr; stk.spillStride = 0;
@@ -625,13 +625,13 @@ static int doWideCheck(Ctx& c, const params::Params& p, uint32_t W, uint32_t H, 
   std::printf("{\"widecheck\": \"%s\", \"closest_rays\": %llu, \"closest_kept\": %llu, \"closest_deferred_by_reference_walk\": %llu, "
               "\"shadow_rays\": %llu, \"shadow_kept\": %llu, \"shadow_deferred_by_reference_walk\": %llu, \"mismatches\": %llu, "
               "\"wide_node_visits\": %llu, \"wide_tri_tests\": %llu, \"ref_box_tests\": %llu, \"ref_tri_tests\": %llu, \"hand_alpha\": %llu, \"hand_tie\": %llu, \"hand_check\": %llu, \"hand_guard\": %llu, "
-              "\"wide_nodes\": %zu, \"wide_node_bytes\": %zu, \"wide_tris\": %zu, \"ref_nodes\": %zu, \"build_ms\": %.1f}\n",
+              "\"wide_nodes\": %zu, \"wide_node_bytes\": %zu, \"wide_tris\": %zu, \"ref_nodes\": %zu, \"build_ms\": %.1f, \"wide_max_stack\": %u}\n",
               bad ? "FAILED" : "ok", (unsigned long long) nClosest, (unsigned long long) keptClosest, (unsigned long long) refDeferC,
               (unsigned long long) nShadow, (unsigned long long) keptShadow, (unsigned long long) refDeferS, (unsigned long long) bad,
               (unsigned long long) st.nodes, (unsigned long long) st.tris, (unsigned long long) refBox, (unsigned long long) refTri,
               (unsigned long long) st.handAlpha, (unsigned long long) st.handTie,
               (unsigned long long) st.handCheck, (unsigned long long) st.handGuard, c.im.wideNodes.size(), wideBytes, c.im.wideTris.size(),
-              c.im.bvhNodes.size(), c.im.wideBuildMs);
+              c.im.bvhNodes.size(), c.im.wideBuildMs, c.im.wideMaxStack);
   return bad ? 4 : 0;
 }
 
@@ -666,8 +666,40 @@ static int doBvhCheck(const char* scenePath, unsigned threads) {
   return 0;
 }
 
+// loadstress: N concurrent host callers of the scene loader and the scene build (what N threads holding their own YartScene
+// handles do on the host before anything reaches a device): .yscn parse, flattening, the task-parallel SAH build with its own
+// worker pool inside every caller, the 8-wide trees. Every caller must arrive at the same image (node array hashed). Run under
+// -fsanitize=thread by tests/test_sanitizers.py: shared mutable state between callers would show as a race.
+static int doLoadStress(const char* scenePath, unsigned callers) {
+  std::vector<uint64_t> sig(callers, 0);
+  std::vector<std::string> err(callers);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < callers; t++)
+    th.emplace_back([&, t] {
+      try {
+        auto loaded = loadSceneFile(scenePath);
+        HostImage im = buildHostImage(loaded->desc);
+        buildWideTrees(im);
+        uint64_t h = 0xcbf29ce484222325ull;
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(im.bvhNodes.data());
+        for (size_t k = 0; k < im.bvhNodes.size() * sizeof(BvhNode); k++) h = (h ^ b[k]) * 0x100000001b3ull;
+        const uint8_t* w = reinterpret_cast<const uint8_t*>(im.wideNodes.data());
+        for (size_t k = 0; k < im.wideNodes.size() * sizeof(Wide8Node); k++) h = (h ^ w[k]) * 0x100000001b3ull;
+        sig[t] = h;
+      } catch (const std::exception& e) { err[t] = e.what(); }
+    });
+  for (auto& x : th) x.join();
+  for (unsigned t = 0; t < callers; t++) {
+    if (!err[t].empty()) { std::fprintf(stderr, "loadstress: caller %u: %s\n", t, err[t].c_str()); return 2; }
+    if (sig[t] != sig[0]) { std::fprintf(stderr, "loadstress: caller %u built a different image\n", t); return 3; }
+  }
+  std::printf("{\"loadstress\": \"ok\", \"callers\": %u, \"signature\": \"%016llx\"}\n", callers, (unsigned long long) sig[0]);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc == 2 && std::string(argv[1]) == "selftest") return doSelfTest();
+  if (argc == 4 && std::string(argv[1]) == "loadstress") return doLoadStress(argv[2], unsigned(std::atoi(argv[3])));
   if (argc == 4 && std::string(argv[1]) == "bvhcheck") return doBvhCheck(argv[2], unsigned(std::atoi(argv[3])));
   if (argc == 6 && std::string(argv[1]) == "estimator")
     return doEstimator(std::atoi(argv[2]), unsigned(std::atoi(argv[3])), argv[4], argv[5]);

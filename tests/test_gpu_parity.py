@@ -532,3 +532,20 @@ def test_texture_footprint_budget_fallback(api, monkeypatch):
     b, _ = full.render(q)
     full.close()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("pipeline", ["wavefront", "wavefront+path_pool", "wavefront+no_compaction"])
+def test_batch_clamp_on_a_small_device_budget(api, pipeline, monkeypatch):
+    """the batch fit bound counts what grows with the batch (path state, tail states, resume records) and takes the
+    fixed allocations (sampler tables, spill / resume ranges) off the budget first; the path pool is clamped the same way. A fake
+    budget of a few MB (YART_FAKE_FREE_MB, read per render) forces the clamp: the render must complete in several batches — not
+    fail in hipMalloc — and give the golden frame."""
+    base = os.path.join(GOLDEN, "cornell")
+    p = load_params(base + ".txt")
+    ref = np.fromfile(base + ".f32", np.float32).reshape(p["size"][1], p["size"][0], 4)
+    scene = api.DeviceScene(base + ".yscn", device=0)
+    monkeypatch.setenv("YART_FAKE_FREE_MB", "48")
+    img, st = scene.render(p, flags=PIPELINE_FLAGS[pipeline])
+    monkeypatch.delenv("YART_FAKE_FREE_MB")
+    bit_identical_or_drift(img, ref, f"cornell/{pipeline} under a 48 MB budget")
+    scene.close()

@@ -47,3 +47,27 @@ def test_wide_walk_equals_reference_order_walk_generated(hostsim, tmp_path, name
         assert out["hand_tie"] > 0          # duplicates at the same t: the reference's order decides, the ray is handed over
     if name in ("alpha_instances", "sponza_class"):
         assert out["hand_alpha"] > 0
+
+
+def test_wide_trees_refused_when_their_walk_could_overflow_the_stack(hostsim, tmp_path):
+    """nothing bounded the depth of the 8-wide trees while the walk's stack is fixed (LDS part + spill area = the
+    reference's 64 entries, ray-integrator.cpp:92-93). The builder now reports the deepest stack a ray can need (one entry per
+    node with two or more inner children on a root-to-leaf path) and a scene whose trees exceed the limit keeps the walk of
+    the reference's tree. A geometric-progression spine is the adversarial shape; the limit is lowered through the environment
+    so that the refusal itself is exercised whatever depth this build reaches."""
+    from yart_amd import scenes
+    s, p = scenes.geometric_spine()
+    sp, pp = str(tmp_path / "s.yscn"), str(tmp_path / "p.txt")
+    s.save(sp); scenes.write_params(pp, p)
+    r = subprocess.run([hostsim, "widecheck", sp, pp, "32", "32", "4"], capture_output=True, text=True)
+    assert r.returncode in (0, 3), r.stderr[-2000:]
+    if r.returncode == 0:
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out["widecheck"] == "ok" and out["mismatches"] == 0 and 1 <= out["wide_max_stack"] <= 62
+        depth = out["wide_max_stack"]
+    else:
+        assert "no 8-wide trees" in r.stderr
+        depth = 63
+    env = dict(os.environ, YART_WIDE_STACK_LIMIT=str(max(0, min(depth, 62) - 1)))
+    r = subprocess.run([hostsim, "widecheck", sp, pp, "32", "32", "4"], capture_output=True, text=True, env=env)
+    assert r.returncode == 3 and "no 8-wide trees" in r.stderr

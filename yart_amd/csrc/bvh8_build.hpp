@@ -51,6 +51,7 @@ static_assert(sizeof(Wide8Node) == 128, "Wide8Node is one cache line");
 
 constexpr uint32_t kWideGrid = 2047;       // largest grid coordinate (integers up to 2048 are exact in half precision)
 constexpr uint32_t kWideLeafMax = 3;
+constexpr uint32_t kWideStackDepth = 64;   // what the walks hold per ray (= traverse.hpp::kRefStackDepth, the reference's own depth, ray-integrator.cpp:92-93)
 
 inline uint16_t halfOfInt(uint32_t q) {    // exact for q <= 2048
   if (q == 0u) return 0u;
@@ -79,6 +80,9 @@ class Bvh8Builder {
   std::vector<uint32_t> order;       // triangle ids in record order (Wide8Node::triBase indexes this)
   // statistics of the last build
   double sahCost = 0.0;
+  // The walk (trace_lean_wide.inc, traverse_wide.hpp) pushes one stack entry per node with more than one pending inner hit: the
+  // deepest stack a ray can need is the largest number of nodes with two or more inner children on a root-to-leaf path.
+  uint32_t maxStack = 0;
 
  private:
   struct BNode { Bounds3 b; uint32_t left = 0, right = 0, first = 0, count = 0; };   // count > 0: leaf
@@ -240,10 +244,11 @@ class Bvh8Builder {
   }
 
   void emit() {
-    struct Item { uint32_t bnode, wide; };
+    struct Item { uint32_t bnode, wide, pend; };     // pend: stack entries a ray can hold when it reaches this node
     std::vector<Item> queue;
     nodes.push_back(Wide8Node{});
-    queue.push_back({0, 0});
+    queue.push_back({0, 0, 0});
+    maxStack = 0;
     std::vector<Child> kids;
     for (size_t qi = 0; qi < queue.size(); qi++) {
       const Item it = queue[qi];
@@ -314,6 +319,10 @@ class Bvh8Builder {
         for (int a = 0; a < 3; a++) { w.planes[a][0][s] = halfOfInt(kWideGrid); w.planes[a][1][s] = halfOfInt(0); }   // empty slot: inverted box
       w.childBase = uint32_t(nodes.size());
       w.triBase = uint32_t(order.size());
+      uint32_t nInner = 0;
+      for (size_t c = 0; c < nc; c++) nInner += inner[c] ? 1u : 0u;
+      const uint32_t pendBelow = it.pend + (nInner >= 2u ? 1u : 0u);
+      if (pendBelow > maxStack) maxStack = pendBelow;
       for (int s = 0; s < 8; s++) {
         const int c = childAt[s];
         if (c < 0) continue;
@@ -325,7 +334,7 @@ class Bvh8Builder {
         }
         if (inner[c]) {
           w.imask |= uint8_t(1u << s);
-          queue.push_back({kids[c].bnode, uint32_t(nodes.size())});
+          queue.push_back({kids[c].bnode, uint32_t(nodes.size()), pendBelow});
           nodes.push_back(Wide8Node{});
         } else {
           for (size_t j = 0; j < tris[c].size(); j++) { w.triValid |= 1u << (3 * s + int(j)); order.push_back(tris[c][j]); }

@@ -41,6 +41,7 @@ struct HostImage {
   std::vector<LeafTri> wideTris;
   bool wideBuilt = false, wideOk = false;          // buildWideTrees has run / every mesh has them (a mesh with non-finite coordinates has not)
   double wideBuildMs = 0.0;
+  uint32_t wideMaxStack = 0;                       // deepest stack a ray can need in any of the 8-wide trees (Bvh8Builder::maxStack)
   std::vector<u4> triVerts;
   std::vector<int32_t> triLight;
   std::vector<f4> vPos, vNormal, vTangent;
@@ -723,6 +724,11 @@ inline CameraDev makeCamera(const YartCameraDesc& c) {
 // and one over the alpha-tested and the NEE-transparent ones (A), built from the flattened image itself (vertex positions, triangle
 // records, the reference's tree for the acceptance check's leaf boxes). Built on first use (YART_FLAG_WIDE_TREES): the default
 // pipeline walks the reference's tree only. Returns HostImage::wideOk.
+// (tests lower the limit through YART_WIDE_STACK_LIMIT to reach the refusal with a small mesh)
+inline uint32_t wideStackLimit() {
+  if (const char* e = std::getenv("YART_WIDE_STACK_LIMIT")) return uint32_t(std::max(0, std::atoi(e)));
+  return kWideStackDepth;
+}
 inline bool buildWideTrees(HostImage& im) {
   if (im.wideBuilt) return im.wideOk;
   im.wideBuilt = true;
@@ -784,6 +790,10 @@ inline bool buildWideTrees(HostImage& im) {
       if (ids.empty()) return true;
       Bvh8Builder b8;
       if (!b8.build(boxes, cent, ids, pad)) return false;
+      // a tree whose walk could need more stack entries than the kernels' stack (LDS part + spill area: kRefStackDepth in all; the
+      // scalar walk's array likewise) is not used: the scene keeps the walk of the reference's tree (wideOk = false)
+      im.wideMaxStack = std::max(im.wideMaxStack, b8.maxStack);
+      if (b8.maxStack + 2u > kWideStackDepth || b8.maxStack > wideStackLimit()) return false;
       const uint32_t nodeBase = uint32_t(im.wideNodes.size()), triBase = uint32_t(im.wideTris.size());
       root = nodeBase;
       for (Wide8Node w : b8.nodes) { w.childBase += nodeBase; w.triBase += triBase; im.wideNodes.push_back(w); }

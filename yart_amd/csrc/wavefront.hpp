@@ -185,16 +185,16 @@ YART_HD void wfGenerate(const RenderConst& rc, const uint32_t* sobol, const Came
 // The Russian roulette + next-bounce decision of a path that cast a shadow ray (mis-integrator.cpp:96-102), after the shadow
 // traversal (whose alpha tests may have drawn sampler dimensions: thr.w is current). `depth` = bounces done, uniform over
 // the launch and >= 2 here. Returns true if the path continues; otherwise its radiance and ray count go to `out`.
-// Where a finished path's radiance goes: record slotMap[slot] of `out` (no map: record `slot`). With a map the slot is then marked
-// free (kWfFreeSlot): in the path pool (wavefront_kernels.inc: k_wf_refill) the map is the slots' path index, and the next round
-// starts a new path in every free slot.
+// Where a finished path's radiance goes: record slotMap[slot] of `out` (no map: record `slot`). The map of the compacted tail
+// states is only read. `pool`: the map is the path pool's (wavefront_kernels.inc: k_wf_refill) — the slots' path index —, and the
+// slot is then marked free (kWfFreeSlot): the next round starts a new path in every free slot.
 constexpr uint32_t kWfFreeSlot = 0xffffffffu;
-YART_HD void wfRetire(f4* out, uint32_t* slotMap, uint32_t slot, f4 record) {
+YART_HD void wfRetire(f4* out, uint32_t* slotMap, uint32_t slot, f4 record, bool pool) {
   uint32_t idx = slot;
-  if (slotMap) { idx = slotMap[slot]; slotMap[slot] = kWfFreeSlot; }
+  if (slotMap) { idx = slotMap[slot]; if (pool) slotMap[slot] = kWfFreeSlot; }
   wfSt(out + idx, record);
 }
-YART_HD bool wfRouletteAfterShadow(const RenderConst& rc, const WfState& s, uint32_t slot, uint32_t depth, f4* out, uint32_t* slotMap) {
+YART_HD bool wfRouletteAfterShadow(const RenderConst& rc, const WfState& s, uint32_t slot, uint32_t depth, f4* out, uint32_t* slotMap, bool pool) {
   const f4 t = wfLd(s.thr + slot);
   WfPath p;
   p.att = mk3(t.x, t.y, t.z);
@@ -207,7 +207,7 @@ YART_HD bool wfRouletteAfterShadow(const RenderConst& rc, const WfState& s, uint
     return true;
   }
   const f4 a = wfLd(s.acc + slot);
-  wfRetire(out, slotMap, slot, mk4(a.x, a.y, a.z, asF(wfPathRays(asU(a.w)))));
+  wfRetire(out, slotMap, slot, mk4(a.x, a.y, a.z, asF(wfPathRays(asU(a.w)))), pool);
   return false;
 }
 
@@ -216,7 +216,7 @@ YART_HD bool wfRouletteAfterShadow(const RenderConst& rc, const WfState& s, uint
 // unoccluded -> L += attPre * (Lif * attOcc * cos / denom), one more ray; occluded -> L += attPre * 0, which only a non-finite
 // throughput makes visible (WF_ATT_NAN); a path whose bounce budget is used up (WF_FINAL) is written out here.
 // Returns 1 if the ray counts (unoccluded).
-YART_HD uint32_t wfShadowCommit(const WfState& s, uint32_t slot, bool occluded, f3 attOcc, f4* out, uint32_t* slotMap) {
+YART_HD uint32_t wfShadowCommit(const WfState& s, uint32_t slot, bool occluded, f3 attOcc, f4* out, uint32_t* slotMap, bool pool) {
   f4 a = wfLd(s.acc + slot);
   uint32_t flags = asU(a.w);
   if (occluded && !(flags & (WF_FINAL | WF_ATT_NAN))) return 0u;
@@ -229,7 +229,7 @@ YART_HD uint32_t wfShadowCommit(const WfState& s, uint32_t slot, bool occluded, 
     const f4 s1 = wfLd(s.sh1 + slot);
     L += mk3(s1.x, s1.y, s1.z) * mk3(0.0f);
   }
-  if (flags & WF_FINAL) wfRetire(out, slotMap, slot, mk4(L.x, L.y, L.z, asF(wfPathRays(flags))));
+  if (flags & WF_FINAL) wfRetire(out, slotMap, slot, mk4(L.x, L.y, L.z, asF(wfPathRays(flags))), pool);
   else wfSt(s.acc + slot, mk4(L.x, L.y, L.z, asF(flags)));
   return occluded ? 0u : 1u;
 }
@@ -278,7 +278,7 @@ YART_HD bool wfExtendFast(const SceneDev& sc, const TravStack& stk, const WfStat
 // (wfShadowCommit). Fast variant: same contract as wfExtendFast. `rays` counts the unoccluded ones.
 template <int MODE>
 YART_HD bool wfShadow(const SceneDev& sc, const RenderConst& rc, const TravStack& stk, const WfState& s,
-                      uint32_t i, WfTally& tally, f4* out, uint32_t* slotMap, uint32_t& rays) {
+                      uint32_t i, WfTally& tally, f4* out, uint32_t* slotMap, bool pool, uint32_t& rays) {
   const f4 r0 = s.ray0[i], s0 = s.sh0[i];
   const f3 from = mk3(r0.x, r0.y, r0.z), to = mk3(s0.x, s0.y, s0.z);
   const f3 dir = normalized(to - from);                     // :140
@@ -298,7 +298,7 @@ YART_HD bool wfShadow(const SceneDev& sc, const RenderConst& rc, const TravStack
   WF_TALLY_TRAV(tally, ac);
   if ((MODE & TRAV_FAST) && ac.deferred) return false;
   if (!(MODE & TRAV_FAST) && smp.dim != dim0) s.thr[i].w = asF(smp.dim);
-  rays += wfShadowCommit(s, i, occluded, attOcc, out, slotMap);
+  rays += wfShadowCommit(s, i, occluded, attOcc, out, slotMap, pool);
   return true;
 }
 

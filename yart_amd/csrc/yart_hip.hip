@@ -37,6 +37,7 @@
 #include "trace_lean_walk.hpp"
 #include "trace_lean_tlas.hpp"
 #include "tonemap.hpp"
+#include "trace_ranges.hpp"
 
 using namespace yart_hip;
 
@@ -52,6 +53,7 @@ constexpr int kSpillDepthMax = int(kRefStackDepth);   // spill area sized for th
 constexpr uint64_t kDefaultBatchPaths = 1ull << 28;   // YartRenderParams::max_batch_paths = 0: 268 M paths (batch-synchronous: 77 GB; path pool: 4.3 GB of per-sample records)
 constexpr uint64_t kDefaultPoolPaths = 1ull << 25;    // YartRenderParams::pool_paths = 0: 33.5 M slots, 5.6 GB
 constexpr int kPoolLag = 4;                            // the host looks at the counters of the round before the previous one (ring of 4)
+static_assert(kWideStackDepth == kRefStackDepth, "bvh8_build.hpp bounds its trees by the stack the walks hold (traverse.hpp)");
 constexpr int kNumCounters = 32;       // [0] rays, [1..4] instrumented tallies, [8..31] debug statistics
 
 thread_local std::string g_lastError;
@@ -577,6 +579,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
                     hipStream_t stream, YartStats* stats, const BatchHook* hook = nullptr) {
   bool aborted = false;
   auto wall0 = std::chrono::high_resolution_clock::now();
+  TraceRange rgRender("yart:render");
   HIP_CHECK(hipSetDevice(s.device));
   const uint32_t W = camDesc.width, H = camDesc.height;
   const CameraDev cam = makeCamera(camDesc);
@@ -686,19 +689,38 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   uint32_t resumeCap = 0;
   const bool compact = !mega && !pool && !(p.flags & YART_FLAG_NO_COMPACTION);
   uint64_t maxPaths = p.max_batch_paths ? p.max_batch_paths : kDefaultBatchPaths;
-  if (!pool && !mega) {
+  uint64_t poolFit = ~0ull;                     // path pool: the slots the device can hold next to the batch's radiance records
+  if (!mega) {
     // (safety only: a device that cannot hold the batch renders smaller ones)
     size_t freeB = 0, totalB = 0;
     HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+    if (const char* e = std::getenv("YART_FAKE_FREE_MB")) freeB = size_t(std::max<long long>(1, std::atoll(e))) << 20;   // (tests of the clamp)
     uint64_t held = uint64_t(s.L.n) * 16 + (uint64_t(s.qA.n) + s.qB.n + s.qS.n + s.qR.n) * 4 + uint64_t(s.resumeRec.n) * 16;
     for (auto& b : s.wf) held += uint64_t(b.n) * 16;
     for (auto& t : s.wfTail) for (auto& b : t) held += uint64_t(b.n) * 16;
     held += (uint64_t(s.wfTailMap[0].n) + s.wfTailMap[1].n) * 4;
     held += uint64_t(s.smpEntries.n) * 8;      // the sampler tables of the previous render stay allocated
-    // with compaction: two tail states of 1/2 and 1/4 of the batch (9 x 16 B + a slot map word each) = 111 B per path
-    const uint64_t perPath = compact ? 287 : 176;
-    const uint64_t fits = std::max<uint64_t>((uint64_t(freeB) + held) * 8 / 10 / perPath, 1u << 20);
-    maxPaths = std::min<uint64_t>(std::min<uint64_t>(maxPaths, fits), kWfMaxPaths);
+    if (std::getenv("YART_FAKE_FREE_MB")) held = 0;
+    // what grows with the batch: 9 x 16 B of path state + 4 queue words + 16 B of radiance = 176 B per path; with compaction two
+    // tail states of 1/2 and 1/4 of the batch (9 x 16 B + a slot map word each) = 111 B more; the resume records of an eighth of
+    // the paths (kResumeWords x 16 B each = 24 B per path). What does not: the sampler tables (8 B x dims per PIXEL of the rank),
+    // the resume records' per-wave ranges and the traversal spill area — taken off the budget first.
+    const uint64_t perPath = (compact ? 287 : 176) + ((p.flags & YART_FLAG_NO_RESUME) ? 0 : (kResumeWords * 16 + 7) / 8);
+    const uint64_t dimsEst = std::min<uint32_t>(256u, (4u + 8u * p.max_depth + 16u + 7u) & ~7u);
+    const uint64_t fixedB = uint64_t(nPix) * dimsEst * 8 + uint64_t(gridMax) * kBlock * (kResumeWords * 16 + uint64_t(kSpillDepthMax) * 8);
+    const uint64_t budget = (uint64_t(freeB) + held) * 8 / 10;
+    const uint64_t avail = budget > fixedB ? budget - fixedB : 0;
+    if (!pool) {
+      const uint64_t fits = std::max<uint64_t>(avail / perPath, 1u << 16);
+      maxPaths = std::min<uint64_t>(std::min<uint64_t>(maxPaths, fits), kWfMaxPaths);
+    } else {
+      // pool: 16 B of radiance per path of the batch + 168 B (+ resume records) per slot of the pool: the batch gets at most half
+      // of the budget, the pool what is left
+      const uint64_t fits = std::max<uint64_t>(avail / 2 / 16, 1u << 16);
+      maxPaths = std::min<uint64_t>(maxPaths, fits);
+      const uint64_t left = avail > std::min<uint64_t>(maxPaths, uint64_t(nPix ? nPix : 1) * waveCap) * 16 ? avail - std::min<uint64_t>(maxPaths, uint64_t(nPix ? nPix : 1) * waveCap) * 16 : 0;
+      poolFit = std::max<uint64_t>(left / (176 + (kResumeWords * 16 + 7) / 8), 64);
+    }
   }
   maxPaths = std::min<uint64_t>(maxPaths, (1ull << 31) - 64);
   uint32_t chunk = uint32_t(std::min<uint64_t>(nPix ? nPix : 1, std::max<uint64_t>(maxPaths / waveCap, 1)));
@@ -712,7 +734,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     const size_t npBatch = size_t(chunk) * waveCap;
     size_t np = npBatch;
     if (pool) {
-      const size_t want = p.pool_paths ? p.pool_paths : kDefaultPoolPaths;
+      const size_t want = std::min<uint64_t>(p.pool_paths ? p.pool_paths : kDefaultPoolPaths, poolFit);
       np = std::max<size_t>(64, (std::min(want, npBatch) + 63) & ~size_t(63));
       poolSlots = uint32_t(np);
       s.poolMap.ensure(np);
@@ -757,6 +779,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     ta.cfg = rc.sampler; ta.pixels = s.pixels.p; ta.nPixels = nPix; ta.dims = dims;
     ta.entries = s.smpEntries.p; ta.hash = s.smpHash.p; ta.sobol1 = s.smpSobol1.p;
     ta.matrix52 = reinterpret_cast<const uint32_t*>(s.dev.lut + LutDev::sobol);
+    TraceRange rg("yart:sampler_tables", stream);
     tShade.begin(stream);
     hipLaunchKernelGGL(k_sampler_tables, dim3(s.numCUs * 8), dim3(kBlock), 0, stream, ta);
     HIP_CHECK(hipGetLastError());
@@ -787,6 +810,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         a.sc = s.dev; a.cam = cam; a.rc = rc; a.pixels = s.pixels.p + c0; a.nPixels = n;
         a.spp = uint32_t(waveSamples); a.sampleOffset = uint32_t(takenBefore); a.L = s.L.p;
         a.cursor = s.cursor.p; a.rays = s.counters.p; a.spill = s.spill.p;
+        TraceRange rgMega("yart:megakernel", stream);
         tMega.begin(stream);
         hipLaunchKernelGGL(k_render_mega, dim3(gridMega), dim3(kBlock), 0, stream, a);
         HIP_CHECK(hipGetLastError());
@@ -812,7 +836,11 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         // know when the batch is done; it reads the counters of the round before the previous one (a copy into pinned memory and
         // an event per round, never waited for) and stops launching when that round left no live path and nothing to start:
         // two or three empty rounds at the end instead of a host synchronisation per round.
-        hipEvent_t evRound[kPoolLag];
+        struct RoundEvents {                      // (destroyed on every way out of the round loop, a thrown HipError included)
+          hipEvent_t ev[kPoolLag] = {};
+          ~RoundEvents() { for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+        } roundEv;
+        hipEvent_t* evRound = roundEv.ev;
         for (int k = 0; k < kPoolLag; k++) HIP_CHECK(hipEventCreateWithFlags(&evRound[k], hipEventDisableTiming));
         const uint64_t maxRounds = (uint64_t(a.nPaths) / a.poolSlots + 2u) * (rc.maxDepth + 1u) + 16u;   // (a path lives at most maxDepth rounds)
         bool done = false;
@@ -872,7 +900,6 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
             if (c[WC_NEXT] == 0u) done = true;                  // no live slot after its refill: nothing left to start either
           }
         }
-        for (int k = 0; k < kPoolLag; k++) (void)hipEventDestroy(evRound[k]);
       } else {
         WfArgs a{};
         a.sc = s.dev; a.cam = cam; a.rc = rcw; a.pixBase = c0;
@@ -898,12 +925,17 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         }
         const uint32_t init[WC_COUNT] = {a.nPaths, 0, 0, 0, 0, 0, 0, 0, 0};
         HIP_CHECK(hipMemcpyAsync(s.wfCounters.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+        TraceRange rgGen("yart:generate", stream);
         tShade.begin(stream);
         hipLaunchKernelGGL(k_wf_generate, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
         HIP_CHECK(hipGetLastError());
         tShade.end(stream);
+        rgGen.end();
         for (uint32_t bounce = 0; bounce < rc.maxDepth; bounce++) {
           a.bounce = bounce;
+          char rgName[32]; std::snprintf(rgName, sizeof(rgName), "yart:bounce %u", bounce);
+          TraceRange rgBounce(rgName);
+          TraceRange rgExtend("yart:extend", stream);
           tExtend.begin(stream);
           if (general) {
             hipLaunchKernelGGL(k_wf_extend<false>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
@@ -917,12 +949,16 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           }
           HIP_CHECK(hipGetLastError());
           tExtend.end(stream);
+          rgExtend.end();
+          TraceRange rgShade("yart:shade", stream);
           tShade.begin(stream);
           tShadeK.begin(stream);
           hipLaunchKernelGGL(kShade, dim3(gridShade), dim3(kShadeBlock), 0, stream, a);
           HIP_CHECK(hipGetLastError());
           tShadeK.end(stream);
           tShade.end(stream);
+          rgShade.end();
+          TraceRange rgShadow("yart:shadow", stream);
           tConnect.begin(stream);
           if (general) {
             hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
@@ -935,9 +971,11 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           }
           HIP_CHECK(hipGetLastError());
           tConnect.end(stream);
+          rgShadow.end();
           // Russian roulette of the paths that cast a shadow ray: from the second bounce on (at depth 1 none applies: k_wf_shade
           // queued them itself), not after the last one (their radiance has been written out by the shadow kernels)
           if (bounce >= 1 && bounce + 1 < rc.maxDepth) {
+            TraceRange rgR("yart:roulette", stream);
             tShade.begin(stream);
             hipLaunchKernelGGL(k_wf_roulette, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
             HIP_CHECK(hipGetLastError());
@@ -947,6 +985,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           HIP_CHECK(hipGetLastError());
           std::swap(a.qA, a.qB);
           if (compact && bounce >= 1 && bounce + 1 < rc.maxDepth) {     // Russian roulette starts thinning at depth 2
+            TraceRange rgC("yart:compact", stream);
             tShade.begin(stream);
             hipLaunchKernelGGL(k_wf_compact, dim3(s.numCUs * YART_STREAM_BLOCKS), dim3(kBlock), 0, stream, a);
             hipLaunchKernelGGL(k_wf_compact_commit, dim3(1), dim3(64), 0, stream, a);
@@ -960,11 +999,13 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
       g.L = s.L.p; g.pixels = s.pixels.p + c0; g.nPixels = n; g.spp = uint32_t(waveSamples); g.width = W;
       g.exposureScale = cam.exposureScale; g.wCurrent = wCurrent; g.wWave = wWave; g.hdr = dOut;
       g.kind = int(p.estimator);
+      TraceRange rgBlend("yart:gmon_blend", stream);
       tGmon.begin(stream);
       hipLaunchKernelGGL(k_gmon_blend, dim3((n + kGmonPixPerBlock - 1) / kGmonPixPerBlock), dim3(kBlock), 0, stream, g);
       HIP_CHECK(hipGetLastError());
       tGmon.end(stream);
       HIP_CHECK(hipStreamSynchronize(stream));
+      rgBlend.end();
       tMega.resolve(); tExtend.resolve(); tShade.resolve(); tConnect.resolve(); tGmon.resolve(); tLean.resolve(); tShadeK.resolve(); tShadowLean.resolve();
       if (hook && *hook) {
         // ray counts of the blocks this batch completed (their pixels' counts of this wave are all in pixRays now)

@@ -32,6 +32,12 @@ with `per_rank` = every rank's device time and stage times and `reduce_ms` = the
                 `valu_busy` (share of the SIMD cycles that issue one) and, for the traversal kernels, `valu_frac` (the
                 box + triangle tests' lane-operations against the peak lane-operation rate)
   cpu_baseline  the compiled reference on the host cores, bounded sample.
+  one_batch     (N = 1) the headline's frame rendered as ONE batch (max_batch_paths = its path count, 152 GB of path state): how
+                rounds 1-4 timed the headline. `value` itself is measured at the library's default (2^28 paths per batch).
+  secondary     (N = 1) BASELINE.json's other configurations at the library's defaults, 1-2 steps each, each with its own parity
+                gate against the compiled reference (a failing gate -> exit status 3) and the shade kernel's roofline:
+                configs[4] McLaren-class 3840x2160 x 512 spp, configs[3]'s per-GPU workload Sponza-class 1080p x 1024 spp,
+                configs[1] Cornell 512x512 x 64 spp through the megakernel. `--no-secondary` skips them.
 """
 from __future__ import annotations
 
@@ -80,8 +86,11 @@ def parse():
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline / parity sample")
     ap.add_argument("--ref-order-spp", type=int, default=1, help="spp of the oracle run that counts box / triangle tests in the reference's traversal order")
     ap.add_argument("--flags", type=int, default=0, help="YART_FLAG_* pipeline variant (A/B experiments)")
-    ap.add_argument("--batch-paths", type=int, default=-1,
-                    help="YartRenderParams::max_batch_paths: -1 (default) = the whole frame as one batch, 0 = the library's default (2^28)")
+    ap.add_argument("--batch-paths", type=int, default=0,
+                    help="YartRenderParams::max_batch_paths: 0 (default) = the library's default (2^28 paths per batch: what a caller gets), "
+                         "-1 = the whole frame as one batch (how rounds 1-4 timed the headline)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary workloads (BASELINE configs[4], [3], [1]) and the one-batch extra of the headline")
     ap.add_argument("--inproc", action="store_true",
                     help="time the in-process form instead: ONE process, yart_hip_multi_render over --gpus devices (a host thread per "
                          "device, the devices' own pixels merged on device 0 with RCCL send / recv: 1/N of the frame's bytes)")
@@ -93,10 +102,10 @@ def parse():
 
 
 def workload(args):
-    """The scene and the render parameters. `--batch-paths` (default: the frame's own path count, i.e. ONE batch — how rounds 1-3
-    measured this workload; 152 GB of path state on the 288 GB device for the 1080p x 256 spp frame) sets
-    YartRenderParams::max_batch_paths; 0 = the library's default, a fixed 2^28 paths per batch (77 GB; this frame then takes two
-    batches and ~10 ms more: profiles/r4_batch_sweep.txt). The frame does not depend on it."""
+    """The scene and the render parameters. `--batch-paths` sets YartRenderParams::max_batch_paths: 0 (default since round 5) = the
+    library's default, a fixed 2^28 paths per batch (77 GB; the 1080p x 256 spp frame then takes two batches); -1 = the frame's own
+    path count, i.e. ONE batch (how rounds 1-4 timed the headline: 152 GB of path state, ~10 ms less per step) — the line carries
+    that figure as the named extra `one_batch`. The frame does not depend on it."""
     from yart_amd import scenes
     scene, p = scenes.sponza_class(args.width, args.height, args.spp, args.depth, tex=args.tex, sky=args.sky)
     frame = args.width * args.height * args.spp
@@ -264,6 +273,110 @@ def cpu_baseline(scene, p, args):
              "sample": f"same scene/camera, {p['size'][0]}x{p['size'][1]}, {args.cpu_spp} spp of {p['spp']}, "
                        f"depth {p['depth']}, {info['seconds']:.1f} s render ({wall:.1f} s incl. BVH build)"}
     return (entry, ref_order), frame
+
+
+def reference_frame(scene, p, spp):
+    """(frame, info, kind) of the compiled reference (or the CPU restatement where it is not built) at `spp` samples per pixel on all
+    host cores — the checker of a secondary workload's parity gate."""
+    import numpy as np
+    from yart_amd import scenes
+    ref = os.path.join(ROOT, "oracle", "_ref", "yart_ref")
+    port = os.path.join(ROOT, "oracle", "_build", "yart_oracle")
+    exe, kind = (ref, "reference") if os.path.exists(ref) else (port, "port")
+    if not os.path.exists(exe):
+        return None, None, None
+    with tempfile.TemporaryDirectory() as td:
+        sp, pp, out = os.path.join(td, "s.yscn"), os.path.join(td, "p.txt"), os.path.join(td, "o.f32")
+        scene.save(sp)
+        q = {k: v for k, v in p.items() if k not in ("shard_tile", "estimator", "start_sample", "stop_sample", "max_batch_paths")}
+        scenes.write_params(pp, dict(q, spp=spp), threads=os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "render", sp, pp, out], capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise SystemExit(f"bench.py: the CPU checker ({exe}) failed: {r.stderr.strip()[-400:]}")
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        info["wall_s"] = wall
+        return np.fromfile(out, np.float32).reshape(p["size"][1], p["size"][0], 4), info, kind
+
+
+def shade_roofline(c, ms_sum, launches, steps):
+    """The shade kernel's roofline entry from the exact counters `c` of one instrumented pass (SURVEY §8(d) B_shade) and its summed
+    HIP-event time over `steps` timed steps."""
+    n_l = max(1, launches // max(1, steps))
+    t = (ms_sum / max(1, launches)) * 1e-3
+    b = 116 * c["shaded_hits"] + 64 * c["shade_entries"] + c["texture_tap_bytes"]
+    e = {"kernel": "k_wf_shade", "bound": "hbm", "peak": HBM_PEAK_GBPS, "avg_launch_ms": round(t * 1e3, 3), "launches_per_step": n_l,
+         "algorithmic_bytes_per_launch": int(b / n_l),
+         "model": "116 B x shaded hits + 64 B x entries + 4 taps x channels x texel bytes per lookup (SURVEY §8(d) B_shade)",
+         "units_per_step": {"shaded_hits": c["shaded_hits"], "entries": c["shade_entries"], "texture_tap_bytes": c["texture_tap_bytes"]}}
+    e["achieved"] = round(e["algorithmic_bytes_per_launch"] / t * 1e-9, 2) if t > 0 else 0.0
+    e["unit"] = "GB/s"
+    e["frac"] = round(e["achieved"] / e["peak"], 5)
+    e["traffic"] = None          # (counter passes are run for the headline workload only)
+    return e
+
+
+def secondary_workloads(args, api, torch, np, headline_scene, headline_p, device):
+    """BASELINE.json's other configurations, timed by the driver's own run of this file: each at the LIBRARY's
+    defaults (max_batch_paths = 0 -> 2^28 paths per batch), each with its own parity gate — the same scene / camera / depth at a
+    bounded sample count on the GPU against the compiled reference's frame — and, for the wavefront pipeline, the shade kernel's
+    roofline from an instrumented pass of the full workload. Returns (list of entries, all gates ok)."""
+    from yart_amd import scenes
+    out, ok = [], True
+    specs = [
+        # (name, BASELINE config, scene factory, pipeline flags, warm-up, steps, parity spp)
+        ("mclaren_class", "configs[4]", lambda: scenes.mclaren_class(3840, 2160, 512, 8, detail=1.0), 0, 1, 1, 1),
+        ("sponza_class", "configs[3]", lambda: (headline_scene, dict(headline_p, spp=1024)), 0, 1, 2, 4),      # the headline's scene and camera at 1024 spp
+        ("cornell", "configs[1]", lambda: scenes.cornell(512, 512, 64, 4), 1, 2, 5, 64),
+    ]
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, cfg, make, flags, warm, steps, pspp in specs:
+        t_make = time.perf_counter()
+        scene, p = make()
+        W, H = p["size"]
+        p = dict(p, max_batch_paths=0)
+        ds = api.DeviceScene(scene, device=device)
+        t_make = time.perf_counter() - t_make
+        fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        for _ in range(warm):
+            ds.render_into(fb, p, flags=flags, stream=stream)
+        torch.cuda.synchronize()
+        ms_shade = 0.0; n_shade = 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = ds.render_into(fb, p, flags=flags, stream=stream)
+            ms_shade += st["ms_shade_kernel"]; n_shade += st["launches_shade_kernel"]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        e = {"workload": "%s (%d triangles) %dx%d, %d spp, %d bounces" % (name, scene.n_triangles, W, H, p["spp"], p["depth"]),
+             "baseline_config": cfg, "pipeline": "megakernel" if flags & 1 else "wavefront", "pipeline_flags": int(st["pipeline_flags"]),
+             "max_batch_paths": 0, "value": round(W * H * p["spp"] * steps / dt * 1e-6, 3), "unit": "Msamples/s", "steps": steps, "warmup": warm,
+             "ms_per_step": round(dt / steps * 1e3, 3), "rays_per_step": int(st["rays"]),
+             "paths_at_bounce": [int(x) for x in st.get("paths_at_bounce", [])][: p["depth"] + 1],
+             "scene_build_s": round(t_make, 2)}
+        # parity gate: `pspp` samples per pixel of the whole frame, GPU against the compiled reference
+        ref, info, kind = reference_frame(scene, p, pspp)
+        if ref is not None:
+            img, _ = ds.render(dict(p, spp=pspp), flags=flags)
+            err = float(np.sqrt(np.mean((np.nan_to_num(img[..., :3]).astype(np.float64) - np.nan_to_num(ref[..., :3])) ** 2)))
+            same = float(np.mean(np.all(img.view(np.uint32) == ref.view(np.uint32), axis=-1)))
+            e["parity"] = {"rmse": err, "identical_pixel_fraction": round(same, 6), "tolerance": RMSE_TOL, "ok": bool(err < RMSE_TOL),
+                           "against": kind, "sample": f"{W}x{H}, {pspp} spp, depth {p['depth']} ({info['wall_s']:.1f} s on {os.cpu_count()} host threads)"}
+            e["cpu_baseline"] = {"value": round(info["msamples_per_s"], 4), "unit": "Msamples/s", "cores": os.cpu_count() or 1, "kind": kind}
+            ok = ok and err < RMSE_TOL
+        ds.close()
+        del fb
+        if not (flags & 1) and not args.no_roofline:
+            ds2 = api.DeviceScene(scene, device=device, instrumented=True)
+            _, c = ds2.render(p, flags=flags)
+            ds2.close()
+            e["rooflines"] = [shade_roofline(c, ms_shade, n_shade, steps)]
+        elif flags & 1:
+            e["rooflines"] = None
+            e["note"] = "one kernel (k_render_mega) walks, shades and connects: there is no separate shade kernel to put a roofline on"
+        out.append(e)
+    return out, ok
 
 
 def visible_gpu_count():
@@ -517,8 +630,9 @@ def main():
                                   "blocks sharded by rank inside the library, one reduce(SUM) of the frame to rank 0 per step",
                    "pipeline_flags": int(last.get("pipeline_flags", args.flags)),
                    "max_batch_paths": int(p.get("max_batch_paths", 0)),
-                   "batches": "the frame is one batch (max_batch_paths = its path count); the library's default of 2^28 paths per batch "
-                              "renders it in two, +1.4 % (profiles/r4_batch_sweep.txt)" if p.get("max_batch_paths", 0) >= W * H * p["spp"]
+                   "batches": "the frame is one batch (max_batch_paths = its path count: 152 GB of path state)" if p.get("max_batch_paths", 0) >= W * H * p["spp"]
+                              else "the library's default (max_batch_paths = 0: 2^28 paths per batch, what a caller gets; `one_batch` = the same "
+                                   "frame as ONE batch, how rounds 1-4 timed it)" if not p.get("max_batch_paths", 0)
                               else "max_batch_paths = %d" % int(p.get("max_batch_paths", 0))},
         "rays_per_step": int(last.get("rays", 0)),
         "paths_at_bounce": [int(x) for x in last.get("paths_at_bounce", [])][: p["depth"] + 1],     # rank 0's live paths entering each bounce
@@ -657,6 +771,34 @@ def main():
         out["stage_ms_per_step"] = {k: round(last[k], 2) for k in
                                     ("ms_extend", "ms_extend_lean", "ms_connect", "ms_shadow_lean", "ms_shade", "ms_shade_kernel", "ms_gmon", "ms_device")}
         out["counts_per_step"] = {k: c[k] for k in ("traversals", "box_tests", "tri_tests", "shaded_hits")}
+    # ---- named extra + the other BASELINE configurations (N = 1 only; every handle above is closed or idle by now) ----
+    if world == 1 and not args.no_secondary and not (args.flags & 5):
+        try:
+            dscene.close()
+        except Exception:
+            pass
+        if not p.get("max_batch_paths", 0):
+            # the headline's frame as ONE batch (rounds 1-4's configuration), same scene, same steps up to 5
+            ds1 = api.DeviceScene(scene, device=local_rank)
+            p1 = dict(p, max_batch_paths=min(W * H * p["spp"], (1 << 31) - 64))
+            n1 = max(1, min(args.steps, 5))
+            ds1.render_into(fb, p1, flags=args.flags, stream=stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                ds1.render_into(fb, p1, flags=args.flags, stream=stream)
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            ds1.close()
+            out["one_batch"] = {"value": round(W * H * p["spp"] * n1 / d1 * 1e-6, 3), "unit": "Msamples/s", "steps": n1, "warmup": 1,
+                                "ms_per_step": round(d1 / n1 * 1e3, 3), "max_batch_paths": int(p1["max_batch_paths"]),
+                                "note": "the same frame as one batch (152 GB of path state): not what a caller gets by default"}
+        del fb
+        torch.cuda.empty_cache()
+        sec, sec_ok = secondary_workloads(args, api, torch, np, scene, p, local_rank)
+        out["secondary"] = sec
+        if not sec_ok:
+            status = 3
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -24,7 +24,16 @@ from tests.conftest import ORACLE_BIN, REF_BIN
 
 REGRESSION_SEEDS = [612, 2364, 2960]
 CPU_SEEDS = list(range(8)) + REGRESSION_SEEDS               # (4: a crowd of 70, 7: of 260 instance nodes)
-GPU_SEEDS = list(range(40)) + [100, 210] + REGRESSION_SEEDS          # (100, 210: crowds of 1000 / 4300 instance nodes)
+def _has_crowd(seed):            # (the rule of scenes.fuzz_case)
+    return seed % 7 == 4 or seed % 13 == 7 or seed % 101 == 100 or seed % 211 == 210
+
+
+# Driver-run share of the fuzz (the evidence class that found round 4's bug should run under the driver's eyes, not only
+# in builder-run sweeps): 400 consecutive seeds + the regression seeds, 40 further seeds of the `extras` family (coincident duplicates,
+# degenerate triangles, extreme scales: every ninth seed) and 40 further crowd seeds (70 .. 4300 instance nodes), x 5 pipelines.
+GPU_SEEDS = list(range(400)) + REGRESSION_SEEDS
+GPU_EXTRA_SEEDS = [s for s in range(400, 5000) if s % 9 == 5][:40]
+GPU_CROWD_SEEDS = [s for s in range(400, 5000) if _has_crowd(s)][:38] + [504, 632]     # (504: 1000 nodes, 632: 4300)
 FUZZ_PIPELINES = {"wavefront": 0, "megakernel": 1, "wavefront+general_trace": 4, "wavefront+wide_trees": 256,
                   "wavefront+path_pool": 512}
 
@@ -148,21 +157,34 @@ def _first_wave(p):
     return min(int(p.get("first_wave", p["spp"])), int(p["spp"]))
 
 
+def _reference_frames(tmp_path, seeds, workers=8):
+    """(scene, params, reference words) per seed; the compiled reference's renders run `workers` at a time (one thread each)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as ex:
+        res = list(ex.map(lambda sd: _reference_frame(tmp_path, sd), seeds))
+    return {sd: (r[0], r[1], r[4]) for sd, r in zip(seeds, res)}
+
+
 @pytest.mark.gpu
-def test_random_scenes_on_device(built, tmp_path):
-    """One test for all seeds (one process, one device context); every mismatch is listed."""
+@pytest.mark.parametrize("family", ["seeds", "extras", "crowds"])
+def test_random_scenes_on_device(built, tmp_path, family):
+    """One test per family (one process, one device context); every mismatch is listed."""
     from yart_amd import api
     assert api.lib().yart_hip_device_count() > 0, "no HIP device: the GPU tests need the real kernels"
+    seeds = {"seeds": GPU_SEEDS, "extras": GPU_EXTRA_SEEDS, "crowds": GPU_CROWD_SEEDS}[family]
     bad = []
-    for seed in GPU_SEEDS:
-        s, p, _, _, ref = _reference_frame(tmp_path, seed)
-        ds = api.DeviceScene(s, device=0)
-        for name, flags in FUZZ_PIPELINES.items():
-            img, st = ds.render(p, flags=flags)
-            g = np.ascontiguousarray(img, np.float32).view(np.uint32).ravel()
-            if not np.array_equal(ref, g):
-                bad.append(f"seed {seed} / {name}: {(ref != g).sum()} of {ref.size} words differ")
-            if int(st["rays"]) != p["_reference_rays"]:
-                bad.append(f"seed {seed} / {name}: {st['rays']} rays, the reference counts {p['_reference_rays']}")
-        ds.close()
-    assert not bad, "\n".join(bad)
+    for c0 in range(0, len(seeds), 64):                      # (references of 64 seeds at a time: bounded memory and files)
+        chunk = seeds[c0:c0 + 64]
+        refs = _reference_frames(tmp_path, chunk)
+        for seed in chunk:
+            s, p, ref = refs[seed]
+            ds = api.DeviceScene(s, device=0)
+            for name, flags in FUZZ_PIPELINES.items():
+                img, st = ds.render(p, flags=flags)
+                g = np.ascontiguousarray(img, np.float32).view(np.uint32).ravel()
+                if not np.array_equal(ref, g):
+                    bad.append(f"seed {seed} / {name}: {(ref != g).sum()} of {ref.size} words differ")
+                if int(st["rays"]) != p["_reference_rays"]:
+                    bad.append(f"seed {seed} / {name}: {st['rays']} rays, the reference counts {p['_reference_rays']}")
+            ds.close()
+    assert not bad, "\n".join(bad[:50])

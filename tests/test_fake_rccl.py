@@ -49,7 +49,7 @@ sys.path.insert(0, {root!r})
 from yart_amd import api
 from tests.paramfile import load_params
 base = {base!r}
-p = load_params(base + ".txt")
+p = dict(load_params(base + ".txt"), shard_tile=16)      # 16 blocks of the 64x64 frame: every rank owns pixels
 res = {{"steps": []}}
 single = api.DeviceScene(base + ".yscn", device=0)
 ref, st0 = single.render(p)

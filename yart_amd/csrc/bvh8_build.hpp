@@ -19,9 +19,11 @@
 //   4. child boxes quantised CONSERVATIVELY onto a per-node grid of 2048 steps per axis (origin p, step 2^e),
 //      stored as half-precision integers so that a plane's slab distance is one v_fma_mix_f32.
 //
-// Node = 128 bytes = one cache line: header 32 B, then per axis the 8 low planes (16 B) and the 8 high planes
-// (16 B): a ray reads its near planes and its far planes of an axis with one 16-byte load each, the address
-// chosen by the sign of its direction (no per-child selects).
+// Node = 128 bytes = one cache line: header 32 B, then 12 bytes per child slot (per axis one word: low plane |
+// high plane << 16). The cooperative walk (trace_lean_coop.inc) puts one lane on each child: the eight lanes of a
+// ray read the header (one address) and their own 12 bytes — the whole line, once — and a rotate by 0 or 16 bits
+// puts the ray's near plane of an axis into the low half of the word (round 4's layout was per axis and per
+// side, for one lane reading all eight children).
 //
 // Conservativeness. A child's grid box contains the child's exact box (union of the reference's padded triangle
 // boxes) grown by `pad` on every side; `pad` covers the difference between the kernel's slab arithmetic
@@ -45,7 +47,8 @@ struct Wide8Node {             // 128 bytes
   uint32_t triBase;            // record index of the first triangle of the leaf children
   uint32_t triValid;           // bit 3 * slot + j: triangle j of the leaf in `slot`; record = triBase + popcount(bits below)
   uint32_t pad;
-  uint16_t planes[3][2][8];    // [axis][0 = low, 1 = high][slot]: grid coordinate 0..2047 as an IEEE half
+  uint32_t child[8][3];        // [slot][axis]: low plane | high plane << 16, grid coordinates 0..2047 as IEEE halves
+  void setPlanes(int slot, int axis, uint32_t lo, uint32_t hi);
 };
 static_assert(sizeof(Wide8Node) == 128, "Wide8Node is one cache line");
 
@@ -59,6 +62,8 @@ inline uint16_t halfOfInt(uint32_t q) {    // exact for q <= 2048
   const uint32_t mant = (q << (10 - m)) & 0x3ffu;
   return uint16_t(((15 + m) << 10) | mant);
 }
+
+inline void Wide8Node::setPlanes(int slot, int axis, uint32_t lo, uint32_t hi) { child[slot][axis] = uint32_t(halfOfInt(lo)) | (uint32_t(halfOfInt(hi)) << 16); }
 
 class Bvh8Builder {
  public:
@@ -316,7 +321,7 @@ class Bvh8Builder {
         for (int a = 0; a < 3; a++) { w.e[a] = uint8_t(e + 127); step[a] = std::ldexp(1.0L, e); }
       }
       for (int s = 0; s < 8; s++)
-        for (int a = 0; a < 3; a++) { w.planes[a][0][s] = halfOfInt(kWideGrid); w.planes[a][1][s] = halfOfInt(0); }   // empty slot: inverted box
+        for (int a = 0; a < 3; a++) w.setPlanes(s, a, kWideGrid, 0);   // empty slot: inverted box
       w.childBase = uint32_t(nodes.size());
       w.triBase = uint32_t(order.size());
       uint32_t nInner = 0;
@@ -330,7 +335,7 @@ class Bvh8Builder {
           const long double clo = (long double)cb[c].mn[a] - pad_, chi = (long double)cb[c].mx[a] + pad_;
           long double ql = std::floor((clo - (long double)w.p[a]) / step[a]), qh = std::ceil((chi - (long double)w.p[a]) / step[a]);
           ql = ql < 0 ? 0 : ql > kWideGrid ? kWideGrid : ql; qh = qh < 0 ? 0 : qh > kWideGrid ? kWideGrid : qh;
-          w.planes[a][0][s] = halfOfInt(uint32_t(ql)); w.planes[a][1][s] = halfOfInt(uint32_t(qh));
+          w.setPlanes(s, a, uint32_t(ql), uint32_t(qh));
         }
         if (inner[c]) {
           w.imask |= uint8_t(1u << s);

@@ -739,7 +739,7 @@ inline bool buildWideTrees(HostImage& im) {
   for (int c = 0; ok && c < 3; c++) { wlo[c] = (&im.nodeWorld[0].x)[c]; whi[c] = (&im.nodeWorld[1].x)[c]; if (!std::isfinite(wlo[c]) || !std::isfinite(whi[c])) ok = false; }
   im.wideNodes.clear(); im.wideTris.clear();
   im.wideNodes.push_back(Wide8Node{});                            // node 0: never a tree's node
-  for (int a = 0; a < 3; a++) for (int s8 = 0; s8 < 8; s8++) { im.wideNodes[0].planes[a][0][s8] = halfOfInt(kWideGrid); im.wideNodes[0].planes[a][1][s8] = 0; }
+  for (int a = 0; a < 3; a++) for (int s8 = 0; s8 < 8; s8++) im.wideNodes[0].setPlanes(s8, a, kWideGrid, 0);
   for (uint32_t mi = 0; ok && mi < im.meshes.size(); mi++) {
     MeshDev& md = im.meshes[mi];
     md.wideRootO = md.wideRootA = kNoWide; md.wideRo = 0.0f;

@@ -84,21 +84,13 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                                           uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
                                           Retry retry, WfTally& tally) {
   constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
-  // TRAV_WIDE (lean kernels only): inside a mesh the lane walks the mesh's own 8-wide trees (trace_lean_wide.inc) instead of the
-  // reference's binary tree; rays whose result could depend on the reference's order go to the general kernel (from the root)
+  // TRAV_WIDE (lean kernels only): inside a mesh the ray is walked through the mesh's own 8-wide trees by a group of eight lanes
+  // (trace_lean_coop.inc) instead of through the reference's binary tree by its own lane; rays whose result could depend on the
+  // reference's order go to the general kernel (from the root)
   constexpr bool kWide = (MODE & TRAV_WIDE) != 0;
   static_assert(!kWide || kFast, "TRAV_WIDE is a variant of the lean (TRAV_FAST) walk");
   constexpr uint32_t kRefill = kWide ? uint32_t(YART_WIDE_REFILL) : kLeanRefill;      // (the names the parts below use)
-  constexpr uint32_t kInnerMin = kWide ? uint32_t(YART_WIDE_INNER_MIN) : kLeanInnerMin;
-  __shared__ uint32_t wideSpreadLds[kWide ? 256 : 1];
-  __shared__ uint8_t widePermLds[kWide ? 2048 : 4];
-  if (kWide) {
-    for (uint32_t k = threadIdx.x; k < 256u; k += blockDim.x) wideSpreadLds[k] = wideSpread(k);
-    for (uint32_t k = threadIdx.x; k < 2048u; k += blockDim.x) widePermLds[k] = uint8_t(widePerm(k >> 8, k & 255u));
-    __syncthreads();
-  }
-  WideSetup ws; ws.o = mk3(0.0f); ws.idir = mk3(1.0f); ws.offX = 32u; ws.offY = 64u; ws.offZ = 96u; ws.octinv = 7u;
-  uint32_t wG = 0, wB = 0, wT = 0, wTB = 0, wTV = 0, wPhase = 1, wRootO = kNoWide;
+  uint32_t wRootA = kNoWide, wRootO = kNoWide;                // the current mesh's trees (kWide)
   bool crossedT = false;                                      // shadow ray: crossed an NEE-transparent triangle while unoccluded
   Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
   f3 attenuation = mk3(1.0f);
@@ -321,14 +313,10 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                 YART_COUNT(nBox, 1);
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
                   if (kWide) {
-                    // tree A (alpha-tested / NEE-transparent triangles) first, then tree O; the root as a group of one
-                    if (!wideSetup(ray, mesh.wideRo, ws)) { YART_COUNT(nHand[3], 1); pendingRetry = true; has = false; }
-                    else {
-                      inMesh = true; meshDidHit = false; stackIdx = 0; wTB = 0u;
-                      wRootO = mesh.wideRootO;
-                      wPhase = mesh.wideRootA != kNoWide ? 0u : 1u;
-                      wG = (wPhase == 0u ? mesh.wideRootA : wRootO) - (7u ^ ws.octinv); wB = 0x800000ffu;
-                    }
+                    // tree A (alpha-tested / NEE-transparent triangles) first, then tree O: walked by a group of eight lanes in part (C)
+                    WideSetup guard;
+                    if (!wideSetup(ray, mesh.wideRo, guard)) { YART_COUNT(nHand[3], 1); pendingRetry = true; has = false; }
+                    else { inMesh = true; meshDidHit = false; stackIdx = 0; wRootA = mesh.wideRootA; wRootO = mesh.wideRootO; }
                     entered = true;
                   } else {
                   inMesh = true; entered = true;
@@ -344,7 +332,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
     }
 
     if constexpr (kWide) {
-#include "trace_lean_wide.inc"
+#include "trace_lean_coop.inc"
     } else {
 #include "trace_lean_bvh2.inc"
     }

@@ -30,13 +30,14 @@ constexpr float kWideIdirMax = 0x1p60f;
 
 struct WideSetup {            // per ray and mesh
   f3 o, idir;
-  uint32_t offX, offY, offZ;  // byte offset of the ray's NEAR planes of each axis within a node (far planes: offset ^ 16)
+  uint32_t shX, shY, shZ;     // 16 where the direction component is negative, else 0: a child's plane word of an axis (low plane | high
+                              // plane << 16) rotated right by it has the ray's NEAR plane in its low half and the FAR plane in its high half
   uint32_t octinv;            // 7 ^ (sign bits of the direction): slot ^ octinv = traversal priority (7 first)
 };
 // false: the ray must be handed over (see above)
 YART_HD bool wideSetup(const RayO& ray, float ro, WideSetup& w) {
   w.o = ray.o; w.idir = ray.idir;
-  w.offX = 32u + (ray.sx ? 16u : 0u); w.offY = 64u + (ray.sy ? 16u : 0u); w.offZ = 96u + (ray.sz ? 16u : 0u);
+  w.shX = ray.sx ? 16u : 0u; w.shY = ray.sy ? 16u : 0u; w.shZ = ray.sz ? 16u : 0u;
   w.octinv = 7u ^ (ray.sx | (ray.sy << 1) | (ray.sz << 2));
   // (comparisons are false for NaN: a NaN anywhere fails)
   return fabsf(ray.idir.x) < kWideIdirMax && fabsf(ray.idir.y) < kWideIdirMax && fabsf(ray.idir.z) < kWideIdirMax &&
@@ -54,7 +55,6 @@ YART_HD uint32_t widePerm(uint32_t octinv, uint32_t b) {
   for (uint32_t s = 0; s < 8; s++) if ((b >> s) & 1u) r |= 1u << (s ^ octinv);
   return r;
 }
-struct WideLuts { const uint32_t* spread; const uint8_t* perm; };   // 256 words; 8 x 256 bytes (device: in LDS)
 
 // fma(float(half k of w), a, b) with one rounding
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -64,9 +64,9 @@ __device__ __forceinline__ float widePlaneLo(uint32_t w, float a, float b) {
 __device__ __forceinline__ float widePlaneHi(uint32_t w, float a, float b) {
   float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(a), "v"(b)); return r;
 }
-__device__ __forceinline__ uint32_t wideShiftIn(uint32_t m, float d) { return __builtin_amdgcn_alignbit(m, __builtin_bit_cast(uint32_t, d), 31); }
-// max / min of four (the operands come out of inline assembly: fmaxf would first canonicalise each of them with a v_max_f32 x, x —
-// 40 instructions per node; no NaN reaches these: wideSetup)
+__device__ __forceinline__ uint32_t wideRotr(uint32_t w, uint32_t sh) { return __builtin_amdgcn_alignbit(w, w, sh); }
+// max / min of four (the operands come out of inline assembly: fmaxf would first canonicalise each of them with a v_max_f32 x, x;
+// no NaN reaches these: wideSetup)
 __device__ __forceinline__ float wideMax4(float a, float b, float c, float d) {
   float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(r), "v"(d)); return r;
 }
@@ -81,10 +81,50 @@ inline float wideHalfValue(uint32_t h) {                     // zero and normal 
 }
 inline float widePlaneLo(uint32_t w, float a, float b) { return __builtin_fmaf(wideHalfValue(w & 0xffffu), a, b); }
 inline float widePlaneHi(uint32_t w, float a, float b) { return __builtin_fmaf(wideHalfValue(w >> 16), a, b); }
-inline uint32_t wideShiftIn(uint32_t m, float d) { return (m << 1) | (__builtin_bit_cast(uint32_t, d) >> 31); }
+inline uint32_t wideRotr(uint32_t w, uint32_t sh) { return sh ? ((w >> sh) | (w << (32u - sh))) : w; }
 inline float wideMax4(float a, float b, float c, float d) { return fmaxf(fmaxf(fmaxf(a, b), c), d); }
 inline float wideMin4(float a, float b, float c, float d) { return fminf(fminf(fminf(a, b), c), d); }
 #endif
+
+#if defined(__HIPCC__)
+// min over the eight lanes of a group (lanes 8g .. 8g + 7, all of them active), returned in all of them: two quad permutes and a
+// mirror of the half row, each fused into its v_min_f32 (DPP): no LDS, no permute unit
+__device__ __forceinline__ float coopMin8(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1, 0, 3, 2]
+  v = fminf(v, a);
+  a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));         // quad_perm [2, 3, 0, 1]
+  v = fminf(v, a);
+  a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));        // row_half_mirror
+  v = fminf(v, a);
+#endif
+  return v;
+}
+#endif
+
+// Per node and ray: the grid step and origin folded into the slab line t = q * s + b of each axis.
+struct WideNodeRay { float sx, sy, sz, bx, by, bz; };
+YART_HD WideNodeRay wideNodeRay(const u4& h0, const WideSetup& r) {
+  WideNodeRay n;
+  // one grid step for the three axes (the largest extent decides it: bvh8_build.hpp)
+  const float step = __builtin_bit_cast(float, (h0.w & 0xffu) << 23);
+  n.sx = r.idir.x * step; n.sy = r.idir.y * step; n.sz = r.idir.z * step;
+  n.bx = (__builtin_bit_cast(float, h0.x) - r.o.x) * r.idir.x;
+  n.by = (__builtin_bit_cast(float, h0.y) - r.o.y) * r.idir.y;
+  n.bz = (__builtin_bit_cast(float, h0.z) - r.o.z) * r.idir.z;
+  return n;
+}
+// One child box (its three plane words) against the ray's interval [tMin, tMax]: true = missed. The ONE place the slab arithmetic of
+// the 8-wide trees is written: the cooperative kernel runs it on one lane per child, the scalar walk below in a loop.
+YART_HD bool wideChildMissed(uint32_t wx, uint32_t wy, uint32_t wz, const WideSetup& r, const WideNodeRay& n, float tMin, float tMax) {
+  const uint32_t rx = wideRotr(wx, r.shX), ry = wideRotr(wy, r.shY), rz = wideRotr(wz, r.shZ);
+  const float tnx = widePlaneLo(rx, n.sx, n.bx), tfx = widePlaneHi(rx, n.sx, n.bx);
+  const float tny = widePlaneLo(ry, n.sy, n.by), tfy = widePlaneHi(ry, n.sy, n.by);
+  const float tnz = widePlaneLo(rz, n.sz, n.bz), tfz = widePlaneHi(rz, n.sz, n.bz);
+  const float lo = wideMax4(tnx, tny, tnz, tMin);
+  const float hi = wideMin4(tfx, tfy, tfz, tMax);
+  return (__builtin_bit_cast(uint32_t, hi - lo) >> 31) != 0u;    // sign bit of hi - lo
+}
 
 struct WideNodeHits {
   uint32_t hitByte;          // slots whose box the ray's interval meets
@@ -92,47 +132,21 @@ struct WideNodeHits {
 };
 // (base: uniform pointer, off: 32-bit byte offset per lane — global_load with a scalar base and a 32-bit vector offset)
 YART_HD u4 wideLd16(const uint8_t* base, uint32_t off) { return *reinterpret_cast<const u4*>(base + off); }
-template <int K> YART_HD uint32_t wideWord(const u4& v) { return K == 0 ? v.x : K == 1 ? v.y : K == 2 ? v.z : v.w; }
+YART_HD uint32_t wideLd4(const uint8_t* base, uint32_t off) { return *reinterpret_cast<const uint32_t*>(base + off); }
+constexpr uint32_t kWideChildOffset = 32u, kWideChildBytes = 12u;   // Wide8Node: header, then 12 bytes per slot
 
-template <int I>
-YART_HD uint32_t wideChild(uint32_t miss, const u4& nx, const u4& fx, const u4& ny, const u4& fy, const u4& nz, const u4& fz,
-                           float sx, float sy, float sz, float bx, float by, float bz, float tMin, float tMax) {
-  const uint32_t wnx = wideWord<I / 2>(nx), wfx = wideWord<I / 2>(fx), wny = wideWord<I / 2>(ny), wfy = wideWord<I / 2>(fy),
-                 wnz = wideWord<I / 2>(nz), wfz = wideWord<I / 2>(fz);
-  float tnx, tfx, tny, tfy, tnz, tfz;
-  if (I & 1) {
-    tnx = widePlaneHi(wnx, sx, bx); tfx = widePlaneHi(wfx, sx, bx); tny = widePlaneHi(wny, sy, by); tfy = widePlaneHi(wfy, sy, by);
-    tnz = widePlaneHi(wnz, sz, bz); tfz = widePlaneHi(wfz, sz, bz);
-  } else {
-    tnx = widePlaneLo(wnx, sx, bx); tfx = widePlaneLo(wfx, sx, bx); tny = widePlaneLo(wny, sy, by); tfy = widePlaneLo(wfy, sy, by);
-    tnz = widePlaneLo(wnz, sz, bz); tfz = widePlaneLo(wfz, sz, bz);
-  }
-  const float lo = wideMax4(tnx, tny, tnz, tMin);
-  const float hi = wideMin4(tfx, tfy, tfz, tMax);
-  return wideShiftIn(miss, hi - lo);                         // sign bit of hi - lo: the slot is missed
-}
-
-// One node against one ray: eight slab tests on the node's grid. tMax: the cull bound (already widened by the caller).
+// One node against one ray, slot by slot (the scalar form). tMax: the cull bound (already widened by the caller).
 YART_HD WideNodeHits wideTestNode(const uint8_t* nodes, uint32_t nidx, const WideSetup& r, float tMin, float tMax) {
   const uint32_t nb = nidx << 7;                                 // (fewer than 2^24 nodes: host_scene.hpp)
   const u4 h0 = wideLd16(nodes, nb), h1 = wideLd16(nodes, nb + 16u);
-  const u4 nx = wideLd16(nodes, nb + r.offX), fx = wideLd16(nodes, nb + (r.offX ^ 16u));
-  const u4 ny = wideLd16(nodes, nb + r.offY), fy = wideLd16(nodes, nb + (r.offY ^ 16u));
-  const u4 nz = wideLd16(nodes, nb + r.offZ), fz = wideLd16(nodes, nb + (r.offZ ^ 16u));
-  const uint32_t ew = h0.w;
-  // one grid step for the three axes (the largest extent decides it: bvh8_build.hpp)
-  const float step = __builtin_bit_cast(float, (ew & 0xffu) << 23);
-  const float sx = r.idir.x * step, sy = r.idir.y * step, sz = r.idir.z * step;
-  const float bx = (__builtin_bit_cast(float, h0.x) - r.o.x) * r.idir.x;
-  const float by = (__builtin_bit_cast(float, h0.y) - r.o.y) * r.idir.y;
-  const float bz = (__builtin_bit_cast(float, h0.z) - r.o.z) * r.idir.z;
-  uint32_t miss = 0;
-#define YW(I) miss = wideChild<I>(miss, nx, fx, ny, fy, nz, fz, sx, sy, sz, bx, by, bz, tMin, tMax)
-  YW(7); YW(6); YW(5); YW(4); YW(3); YW(2); YW(1); YW(0);      // slot 0 ends in bit 0
-#undef YW
+  const WideNodeRay n = wideNodeRay(h0, r);
   WideNodeHits o;
-  o.hitByte = ~miss & 0xffu;
-  o.imask = ew >> 24; o.childBase = h1.x; o.triBase = h1.y; o.triValid = h1.z;
+  o.hitByte = 0;
+  for (uint32_t s = 0; s < 8u; s++) {
+    const uint32_t cb = nb + kWideChildOffset + kWideChildBytes * s;
+    if (!wideChildMissed(wideLd4(nodes, cb), wideLd4(nodes, cb + 4u), wideLd4(nodes, cb + 8u), r, n, tMin, tMax)) o.hitByte |= 1u << s;
+  }
+  o.imask = h0.w >> 24; o.childBase = h1.x; o.triBase = h1.y; o.triValid = h1.z;
   return o;
 }
 
@@ -145,28 +159,43 @@ YART_HD bool wideLeafCheck(const SceneDev& sc, const RayO& ray, float tMin, floa
 
 enum : uint32_t { WIDE_REJECT = 0, WIDE_ACCEPT = 1, WIDE_TRANSPARENT = 2,
                   WIDE_HANDOVER = 4, WIDE_HAND_ALPHA = 4, WIDE_HAND_TIE = 5, WIDE_HAND_CHECK = 6, WIDE_HAND_NAN = 7 };   // >= WIDE_HANDOVER: hand the ray over
-// One triangle of a tree O (no alpha-tested triangles) / of a tree A (alpha-tested and NEE-transparent ones only).
+
+// The reference's Moeller-Trumbore test (cpu/ray-integrator.cpp:163-196), operation for operation, up to the point where it has t:
+// 0 = rejected by the determinant or the barycentrics, 1 = t / u / v / det are the reference's values, 2 = t is NaN (the reference
+// accepts a NaN t: both of its interval comparisons are false).
+struct WideCand { float t, u, v, det; };
+YART_HD uint32_t wideTriTest(const LeafTri& tr, const f3& o, const f3& d, WideCand& c) {
+  const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
+  const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
+  const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
+  const f3 rayEdge2 = cross(d, edge2);
+  const float det = dot(edge1, rayEdge2);
+  if (double(fabsf(det)) < 1e-12) return 0u;
+  const float invDet = 1.0f / det;
+  const f3 b = o - p0;
+  const float u = dot(b, rayEdge2) * invDet;
+  if (u < 0.0f || u > 1.0f) return 0u;
+  const f3 bEdge1 = cross(b, edge1);
+  const float v = dot(d, bEdge1) * invDet;
+  if (v < 0.0f || u + v > 1.0f) return 0u;
+  const float t = dot(edge2, bEdge1) * invDet;
+  c.t = t; c.u = u; c.v = v; c.det = det;
+  return t == t ? 1u : 2u;
+}
+
+// One triangle of a tree O (no alpha-tested triangles) / of a tree A (alpha-tested and NEE-transparent ones only), one after the
+// other (the scalar walk; the cooperative kernel applies the same rules to the candidates of a round together).
 // O: closest hit -> hit updated on WIDE_ACCEPT; NEE -> WIDE_ACCEPT = occluded (hit untouched), transparent triangles are no occluders.
 // A: WIDE_HAND_ALPHA for a crossing that matters, WIDE_TRANSPARENT for a transparent crossing of a shadow ray, else WIDE_REJECT.
 template <bool NEE, bool TREE_A>
 YART_HD uint32_t wideTriangle(const SceneDev& sc, const LeafTri& tr, const RayO& ray, float tMin, HitRec& hit, bool meshDidHit, uint32_t nodeI) {
   if (!TREE_A && NEE && (tr.matFlags & MAT_TRANSPARENT)) return WIDE_REJECT;
   if (TREE_A && !NEE && !(tr.matFlags & MAT_HAS_ALPHA)) return WIDE_REJECT;     // (transparent: an ordinary surface for a closest-hit ray, found in O)
-  const f3 p0 = mk3(tr.p0[0], tr.p0[1], tr.p0[2]);
-  const f3 edge1 = mk3(tr.e1[0], tr.e1[1], tr.e1[2]);
-  const f3 edge2 = mk3(tr.e2[0], tr.e2[1], tr.e2[2]);
-  const f3 rayEdge2 = cross(ray.d, edge2);
-  const float det = dot(edge1, rayEdge2);
-  if (double(fabsf(det)) < 1e-12) return WIDE_REJECT;
-  const float invDet = 1.0f / det;
-  const f3 b = ray.o - p0;
-  const float u = dot(b, rayEdge2) * invDet;
-  if (u < 0.0f || u > 1.0f) return WIDE_REJECT;
-  const f3 bEdge1 = cross(b, edge1);
-  const float v = dot(ray.d, bEdge1) * invDet;
-  if (v < 0.0f || u + v > 1.0f) return WIDE_REJECT;
-  const float t = dot(edge2, bEdge1) * invDet;
-  if (!(t == t)) return WIDE_HAND_NAN;                       // (the reference accepts a NaN t: both of its comparisons are false)
+  WideCand c;
+  const uint32_t r = wideTriTest(tr, ray.o, ray.d, c);
+  if (r == 0u) return WIDE_REJECT;
+  if (r == 2u) return WIDE_HAND_NAN;
+  const float t = c.t;
   if (TREE_A) {
     if (t <= tMin || hit.t <= t) return WIDE_REJECT;
     if (tr.matFlags & MAT_HAS_ALPHA) return WIDE_HAND_ALPHA;
@@ -176,8 +205,8 @@ YART_HD uint32_t wideTriangle(const SceneDev& sc, const LeafTri& tr, const RayO&
   if (hit.t == t) return (!NEE && meshDidHit) ? WIDE_HAND_TIE : WIDE_REJECT;   // a tie within the mesh: the reference's order decides
   if (!wideLeafCheck(sc, ray, tMin, t, tr.matFlags)) return WIDE_HAND_CHECK;
   if (!NEE) {
-    hit.t = t; hit.u = u; hit.v = v; hit.tri = tr.triIdx; hit.node = nodeI;
-    hit.backSide = (det < 0 ? 1u : 0u) | (tr.material << 1);
+    hit.t = t; hit.u = c.u; hit.v = c.v; hit.tri = tr.triIdx; hit.node = nodeI;
+    hit.backSide = (c.det < 0 ? 1u : 0u) | (tr.material << 1);
   }
   return WIDE_ACCEPT;
 }

@@ -159,12 +159,12 @@ typedef struct YartRenderParams {
 #define YART_FLAG_NO_RESUME 128u    /* rays the lean traversal kernels hand to the general ones are traced again from the root instead of
                                        being taken up where the lean kernel stood (the default; same frame either way) */
 #define YART_FLAG_GENERAL_TRACE 4u  /* general traversal kernels for every ray instead of lean kernels + retry */
-#define YART_FLAG_WIDE_TREES 256u   /* ABI 3: the lean traversal kernels walk their own 8-wide trees (csrc/bvh8_build.hpp) instead of the
-                                       reference's binary tree in the reference's order (the default); rays whose result could depend on
-                                       that order are handed to the general kernels. Same frame either way */
+/* value 256 (YART_FLAG_WIDE_TREES of rounds 4-5: 8-wide trees of the lean kernels' own, walked one ray per lane, then by eight lanes per
+   ray) is retired and ignored: both forms were bit-identical and slower than the walk of the reference's tree
+   (profiles/r4_ab_lean_tree.txt, profiles/r5_ab_coop_tree.txt) */
 #define YART_FLAG_PATH_POOL 512u    /* ABI 3: run a batch through a pool of pool_paths path slots with path regeneration (a slot whose path has ended
                                        takes the batch's next path) instead of one slot per path of the batch. Same frame either way */
-/* ABI history. 3: YART_FLAG_WIDE_TREES, YART_FLAG_PATH_POOL; YartStats grew (wide_* fields at the end); value 128 has meant NO_RESUME since the end of
+/* ABI history. 3: YART_FLAG_PATH_POOL (and the since-retired value 256); YartStats grew (wide_* fields at the end, now always 0); value 128 has meant NO_RESUME since the end of
  * ABI 2 (it selected a since-removed 4-wide re-layout before: an old client passing it gets the same frame, a little slower);
  * YartRenderParams grew (pool_paths); max_batch_paths = 0 now means a fixed 2^28 paths, no longer a share of the free device memory; value 1024 is retired and ignored; YartTileInfo.rays is a real count; yart_hip_multi_render_tiles was added. */
 
@@ -199,10 +199,7 @@ typedef struct YartStats {
   /* instrumented build: rays the lean kernels abandoned at an alpha-tested / transparent candidate and the general
      kernels traced again from the root (they are counted in lean_traversals / shadow_lean_traversals as well) */
   uint64_t retry_extend_traversals, retry_shadow_traversals;
-  /* ABI 3, instrumented build: the lean kernels' walk of their own 8-wide trees — node visits (8 slab tests each) and triangle
-     tests of the closest-hit / the shadow kernel, and the rays handed to the general kernels by cause: [0] crossed an alpha-tested
-     (shadow rays: or, unoccluded, an NEE-transparent) triangle, [1] two candidates at the same t, [2] acceptance check against the
-     reference's leaf box, [3] ray outside the trees' guard (non-finite slab set-up, origin bound) or NaN t */
+  /* ABI 3: counters of the retired 8-wide walk (value 256 above); kept for the layout, always 0 */
   uint64_t wide_extend_nodes, wide_extend_tris, wide_shadow_nodes, wide_shadow_tris;
   uint64_t wide_extend_handed[4], wide_shadow_handed[4];
   /* ABI 3, batch-synchronous wavefront pipeline: paths of this rank that entered bounce b (b < 16; [0] = every path), summed over

@@ -21,7 +21,6 @@
 #include "../../yart_amd/csrc/tonemap.hpp"
 #include "../../yart_amd/csrc/integrator.hpp"
 #include "../../yart_amd/csrc/scene_file.hpp"
-#include "../../yart_amd/csrc/traverse_wide.hpp"
 
 using namespace yart_hip;
 
@@ -484,157 +483,6 @@ static int doEstimator(int kind, unsigned spp, const char* in, const char* out) 
 }
 
 
-// widecheck: the lean kernels' walk of their own 8-wide trees (traverse_wide.hpp::wideTraverseMesh, the scalar form of
-// trace_lean_wide.inc) against the reference-order walk (traverse.hpp, TRAV_FAST: it reports the rays that meet an alpha /
-// transparent candidate in the reference's order) on camera rays, bounce rays and shadow rays of a scene. A ray the wide walk
-// keeps must give the reference-order result bit for bit, and must not be one the reference-order walk defers.
-template <bool NEE>
-static int sceneWide(const SceneDev& sc, f3 o, f3 d, float tMin, HitRec& hit, bool& didHitOut, WideWalkStats& st) {
-  bool didHit = false, crossedT = false;
-  uint32_t i = 0;
-  NodeRayCache cache;
-  RayO ray;
-  bool rayIsWorld = false;
-  while (i < sc.nNodes) {
-    const NodeDev& nd = sc.nodes[i];
-    if (nd.pad[0] & 1u) {
-      if (!rayIsWorld) { ray = makeRay(o + 0.0f, d + 0.0f); rayIsWorld = true; }
-    } else {
-      f3 oo, od;
-      nodeObjectRay(sc, i, nd, o, d, cache, oo, od);
-      ray = makeRay(oo, od);
-      rayIsWorld = false;
-    }
-    float dd;
-    if (!testBox(ray, tMin, hit.t, nd.bmin, nd.bmax, dd) || hit.t < dd) { i = nd.skip; continue; }
-    if (nd.mesh >= 0) {
-      const MeshDev& mesh = sc.meshes[nd.mesh];
-      if (!(NEE && didHit && !mesh.hasAlpha)) {
-        const BvhNode root = sc.bvhNodes[mesh.nodeOffset];
-        float dr;
-        if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, dr)) {               // testBVH's entry test (ray-integrator.cpp:95)
-          bool mdh = false;
-          if (!wideTraverseMesh<NEE>(sc, mesh, i, ray, tMin, hit, mdh, didHit, crossedT, &st)) return 1;
-          didHit |= mdh;
-        }
-      }
-    }
-    i++;
-  }
-  if (NEE && !didHit && crossedT) return 1;
-  didHitOut = didHit;
-  return 0;
-}
-
-static int doWideCheck(Ctx& c, const params::Params& p, uint32_t W, uint32_t H, uint32_t fan) {
-  if (!c.im.wideOk) { std::fprintf(stderr, "widecheck: the scene has no 8-wide trees (deepest stack a tree would need: %u)\n", c.im.wideMaxStack); return 3; }
-  const SceneDev& sc = c.sc;
-  std::vector<uint64_t> stack(kRefStackDepth);
-  TravStack stk; stk.lds = stack.data(); stk.ldsStride = 1; stk.ldsDepth = kRefStackDepth; stk.spill = nullptr; stk.spillStride = 0;
-  WideWalkStats st;
-  uint64_t nClosest = 0, nShadow = 0, keptClosest = 0, keptShadow = 0, refDeferC = 0, refDeferS = 0, bad = 0;
-  uint64_t refBox = 0, refTri = 0;
-  uint32_t lcg = 12345u;
-  auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return float(lcg >> 8) * (1.0f / 16777216.0f); };
-  auto closest = [&](f3 o, f3 d, HitRec& out, bool& hitOut) -> bool {     // returns true if both walks kept the ray
-    nClosest++;
-    HitRec hr; hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
-    f3 att = mk3(1.0f);
-    AlphaCtx ac; ac.sampler = nullptr; ac.cfg = SamplerConfig{};
-    const bool rh = traverseScene<false, TRAV_FAST>(sc, o, d, 0.001f, hr, att, stk, ac);
-#if defined(YART_COUNT_TRAVERSAL)
-    refBox += ac.nBox; refTri += ac.nTri;
-#endif
-    if (ac.deferred) refDeferC++;
-    HitRec hw; hw.t = kInf; hw.u = hw.v = 0; hw.tri = 0; hw.node = 0; hw.backSide = 0;
-    bool wh = false;
-    const int handed = sceneWide<false>(sc, o, d, 0.001f, hw, wh, st);
-    if (handed) return false;
-    keptClosest++;
-    bool rh2 = rh;
-    if (ac.deferred) {
-      // the reference-order lean walk defers at the first alpha candidate it meets; the wide walk kept the ray, so the general walk
-      // must not draw a sampler dimension for it
-      Sampler smp; startPixelSample(smp, c.rc.sampler, 0, 0, 0);
-      const uint32_t dim0 = smp.dim;
-      AlphaCtx ag; ag.sampler = &smp; ag.cfg = c.rc.sampler;
-      hr.t = kInf; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
-      rh2 = traverseScene<false>(sc, o, d, 0.001f, hr, att, stk, ag);
-      if (smp.dim != dim0) { bad++; std::fprintf(stderr, "widecheck: closest-hit ray kept by the wide walk, but the reference's walk draws for an alpha test\n"); return false; }
-    }
-    const bool rhF = rh2;
-    const bool same = rhF == wh && (!rhF || (std::memcmp(&hr.t, &hw.t, 4) == 0 && std::memcmp(&hr.u, &hw.u, 4) == 0 && std::memcmp(&hr.v, &hw.v, 4) == 0 &&
-                                           hr.tri == hw.tri && hr.node == hw.node && hr.backSide == hw.backSide));
-    if (!same) {
-      bad++;
-      if (bad < 10) std::fprintf(stderr, "widecheck: closest hit differs: ref %d t=%.9g tri=%u node=%u | wide %d t=%.9g tri=%u node=%u\n", int(rh), hr.t, hr.tri, hr.node, int(wh), hw.t, hw.tri, hw.node);
-      return false;
-    }
-    out = hr; hitOut = rhF;
-    return true;
-  };
-  auto shadow = [&](f3 from, f3 to) {
-    nShadow++;
-    const f3 dir = normalized(to - from);
-    const float tMax = length(to - from) - 0.001f;
-    HitRec hr; hr.t = tMax; hr.u = hr.v = 0; hr.tri = 0; hr.node = 0; hr.backSide = 0;
-    f3 att = mk3(1.0f);
-    AlphaCtx ac; ac.sampler = nullptr; ac.cfg = SamplerConfig{};
-    const bool ro = traverseScene<true, TRAV_FAST>(sc, from, dir, 0.001f, hr, att, stk, ac);
-    if (ac.deferred) refDeferS++;
-    HitRec hw; hw.t = tMax; hw.u = hw.v = 0; hw.tri = 0; hw.node = 0; hw.backSide = 0;
-    bool wo = false;
-    if (sceneWide<true>(sc, from, dir, 0.001f, hw, wo, st)) return;
-    keptShadow++;
-    bool roF = ro;
-    if (ac.deferred) {
-      // deferred by the reference-order lean walk (an alpha / transparent candidate before occlusion) but kept by the wide walk:
-      // the general walk must then neither draw nor leave an attenuation that is used (unoccluded with attenuation != 1)
-      Sampler smp; startPixelSample(smp, c.rc.sampler, 0, 0, 0);
-      const uint32_t dim0 = smp.dim;
-      AlphaCtx ag; ag.sampler = &smp; ag.cfg = c.rc.sampler;
-      hr.t = tMax; att = mk3(1.0f);
-      roF = traverseScene<true>(sc, from, dir, 0.001f, hr, att, stk, ag);
-      if (smp.dim != dim0 || (!roF && !(att.x == 1.0f && att.y == 1.0f && att.z == 1.0f))) {
-        bad++; std::fprintf(stderr, "widecheck: shadow ray kept by the wide walk, but the reference's walk draws / attenuates\n"); return;
-      }
-    }
-    const bool roK = roF;
-    if (roK != wo) { bad++; if (bad < 10) std::fprintf(stderr, "widecheck: occlusion differs: ref %d wide %d\n", int(roK), int(wo)); }
-  };
-  for (uint32_t y = 0; y < H; y++)
-    for (uint32_t x = 0; x < W; x++) {
-      f3 o, d;
-      cameraRay(c.cam, x * (p.width / W), y * (p.height / H), mk2(0.5f, 0.5f), mk2(0.5f, 0.5f), o, d);
-      HitRec h; bool did = false;
-      if (!closest(o, d, h, did) || !did) continue;
-      const f3 pt = o + h.t * d;
-      for (uint32_t k = 0; k < fan; k++) {
-        // a direction on the sphere; every fourth one axis-aligned in one component (zero direction components)
-        const float z = 2.0f * rnd() - 1.0f, phi = 6.2831853f * rnd(), r = std::sqrt(std::max(0.0f, 1.0f - z * z));
-        f3 dir = mk3(r * std::cos(phi), z, r * std::sin(phi));
-        if (k % 4 == 3) dir.x = 0.0f;
-        dir = normalized(dir);
-        const f3 from = pt + 0.002f * dir;
-        HitRec h2; bool did2 = false;
-        closest(from, dir, h2, did2);
-        shadow(from, from + (k % 2 ? 200.0f : 1.0f + 20.0f * rnd()) * dir);
-      }
-    }
-  size_t wideBytes = c.im.wideNodes.size() * sizeof(Wide8Node);
-  std::printf("{\"widecheck\": \"%s\", \"closest_rays\": %llu, \"closest_kept\": %llu, \"closest_deferred_by_reference_walk\": %llu, "
-              "\"shadow_rays\": %llu, \"shadow_kept\": %llu, \"shadow_deferred_by_reference_walk\": %llu, \"mismatches\": %llu, "
-              "\"wide_node_visits\": %llu, \"wide_tri_tests\": %llu, \"ref_box_tests\": %llu, \"ref_tri_tests\": %llu, \"hand_alpha\": %llu, \"hand_tie\": %llu, \"hand_check\": %llu, \"hand_guard\": %llu, "
-              "\"wide_nodes\": %zu, \"wide_node_bytes\": %zu, \"wide_tris\": %zu, \"ref_nodes\": %zu, \"build_ms\": %.1f, \"wide_max_stack\": %u}\n",
-              bad ? "FAILED" : "ok", (unsigned long long) nClosest, (unsigned long long) keptClosest, (unsigned long long) refDeferC,
-              (unsigned long long) nShadow, (unsigned long long) keptShadow, (unsigned long long) refDeferS, (unsigned long long) bad,
-              (unsigned long long) st.nodes, (unsigned long long) st.tris, (unsigned long long) refBox, (unsigned long long) refTri,
-              (unsigned long long) st.handAlpha, (unsigned long long) st.handTie,
-              (unsigned long long) st.handCheck, (unsigned long long) st.handGuard, c.im.wideNodes.size(), wideBytes, c.im.wideTris.size(),
-              c.im.bvhNodes.size(), c.im.wideBuildMs, c.im.wideMaxStack);
-  return bad ? 4 : 0;
-}
-
 // bvhcheck: the task-parallel BVH build against the plain recursion, every mesh of a scene, byte for byte
 static int doBvhCheck(const char* scenePath, unsigned threads) {
   auto loaded = loadSceneFile(scenePath);
@@ -668,7 +516,7 @@ static int doBvhCheck(const char* scenePath, unsigned threads) {
 
 // loadstress: N concurrent host callers of the scene loader and the scene build (what N threads holding their own YartScene
 // handles do on the host before anything reaches a device): .yscn parse, flattening, the task-parallel SAH build with its own
-// worker pool inside every caller, the 8-wide trees. Every caller must arrive at the same image (node array hashed). Run under
+// worker pool inside every caller. Every caller must arrive at the same image (node array hashed). Run under
 // -fsanitize=thread by tests/test_sanitizers.py: shared mutable state between callers would show as a race.
 static int doLoadStress(const char* scenePath, unsigned callers) {
   std::vector<uint64_t> sig(callers, 0);
@@ -679,12 +527,11 @@ static int doLoadStress(const char* scenePath, unsigned callers) {
       try {
         auto loaded = loadSceneFile(scenePath);
         HostImage im = buildHostImage(loaded->desc);
-        buildWideTrees(im);
         uint64_t h = 0xcbf29ce484222325ull;
         const uint8_t* b = reinterpret_cast<const uint8_t*>(im.bvhNodes.data());
         for (size_t k = 0; k < im.bvhNodes.size() * sizeof(BvhNode); k++) h = (h ^ b[k]) * 0x100000001b3ull;
-        const uint8_t* w = reinterpret_cast<const uint8_t*>(im.wideNodes.data());
-        for (size_t k = 0; k < im.wideNodes.size() * sizeof(Wide8Node); k++) h = (h ^ w[k]) * 0x100000001b3ull;
+        const uint8_t* l = reinterpret_cast<const uint8_t*>(im.leafTris.data());
+        for (size_t k = 0; k < im.leafTris.size() * sizeof(LeafTri); k++) h = (h ^ l[k]) * 0x100000001b3ull;
         sig[t] = h;
       } catch (const std::exception& e) { err[t] = e.what(); }
     });
@@ -705,22 +552,6 @@ int main(int argc, char** argv) {
     return doEstimator(std::atoi(argv[2]), unsigned(std::atoi(argv[3])), argv[4], argv[5]);
   if (argc == 8 && std::string(argv[1]) == "tonemap")
     return doTonemap(argv[2], unsigned(std::atoi(argv[3])), unsigned(std::atoi(argv[4])), argv[5], argv[6], argv[7]);
-  if (argc == 7 && std::string(argv[1]) == "widecheck") {
-    try {
-      auto loaded = loadSceneFile(argv[2]);
-      auto p = params::load(argv[3]);
-      Ctx c;
-      c.im = buildHostImage(loaded->desc);
-      buildWideTrees(c.im);
-      c.sc = c.im.view();
-      c.cam = makeCamera(cameraDesc(p));
-      c.rc.sampler = makeSamplerConfig(p.spp, p.tile);
-      return doWideCheck(c, p, unsigned(std::atoi(argv[4])), unsigned(std::atoi(argv[5])), unsigned(std::atoi(argv[6])));
-    } catch (const std::exception& e) {
-      std::fprintf(stderr, "hostsim: %s\n", e.what());
-      return 2;
-    }
-  }
   if (argc != 5) {
     std::fprintf(stderr, "usage: hostsim kat|render <scene.yscn> <params.txt> <out>\n");
     return 1;

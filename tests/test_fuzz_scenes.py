@@ -6,8 +6,8 @@ reference's bit for bit, for every seed.
 
 CPU: the device headers compiled for the host (tests/hostsim) on a few seeds — the plain path tracer, and the one that sends
 every ray through the lean kernels' walk first (hostsim_lean; it also checks every ray that walk keeps against the general
-walk). GPU: more seeds x the pipelines that trace and shade differently (wavefront, megakernel, general tracers only, 8-wide
-trees, path pool), through the C ABI.
+walk). GPU: more seeds x the pipelines that trace and shade differently (wavefront, megakernel, general tracers only, hand-overs
+restarted instead of resumed, path pool), through the C ABI.
 
 REGRESSION_SEEDS: scenes on which this fuzz found the lean shadow walk missing alpha candidates the reference draws for (an
 occluded ray kept accepting hits: a shorter interval than the reference's, and the first-triangle rule of
@@ -34,7 +34,7 @@ def _has_crowd(seed):            # (the rule of scenes.fuzz_case)
 GPU_SEEDS = list(range(400)) + REGRESSION_SEEDS
 GPU_EXTRA_SEEDS = [s for s in range(400, 5000) if s % 9 == 5][:40]
 GPU_CROWD_SEEDS = [s for s in range(400, 5000) if _has_crowd(s)][:38] + [504, 632]     # (504: 1000 nodes, 632: 4300)
-FUZZ_PIPELINES = {"wavefront": 0, "megakernel": 1, "wavefront+general_trace": 4, "wavefront+wide_trees": 256,
+FUZZ_PIPELINES = {"wavefront": 0, "megakernel": 1, "wavefront+general_trace": 4, "wavefront+no_resume": 128,
                   "wavefront+path_pool": 512}
 
 

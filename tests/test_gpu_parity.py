@@ -37,9 +37,6 @@ PIPELINE_FLAGS = {"wavefront": 0, "megakernel": 1, "wavefront+shade_sort": 2, "w
                   "wavefront+no_shade_sort": 64,
                   # rays the lean kernels hand over are traced again from the root instead of being resumed
                   "wavefront+no_resume": 128,
-                  # the lean kernels walk their own 8-wide trees (quantised child boxes, octant order) instead of the reference's
-                  # binary tree in its order; rays that could depend on that order go to the general kernels
-                  "wavefront+wide_trees": 256,
                   # a pool of path slots with path regeneration instead of one slot per path of the batch
                   "wavefront+path_pool": 512,
                   # scenes of 64 nodes and more take their candidate windows from the top-level hierarchy by default; the two

@@ -36,10 +36,6 @@ def test_host_build_is_clean_under_asan_and_ubsan(san, tmp_path):
     r = subprocess.run([san, "render", base + ".yscn", base + ".txt", out], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-800:]
     assert np.array_equal(np.fromfile(out, np.uint32), np.fromfile(base + ".f32", np.uint32))
-    # the 8-wide tree build (bvh8_build.hpp) and the scalar form of its walk (traverse_wide.hpp) on a scene with both trees
-    r = subprocess.run([san, "widecheck", base + ".yscn", base + ".txt", "24", "16", "4"], capture_output=True, text=True, env=env)
-    assert r.returncode == 0 and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-800:]
-    assert '"widecheck": "ok"' in r.stdout
 
 
 IMPORT_SAN = os.path.join(ROOT, "tests", "hostsim", "_build", "import_san")
@@ -157,7 +153,7 @@ def test_threaded_host_code_is_clean_under_tsan(tsan, tmp_path):
     """SURVEY §5 "Race detection": the reference has none and carries races of exactly the class this build met twice (workers
     reading the wave number unlocked, tile-renderer.hpp:161-162; totalRays added up before the buffer lock, :217-218). The host
     code here that runs on several threads — the task-parallel SAH build (multi-threaded binning above 4096 triangles, subtree
-    tasks below), concurrent callers of the scene loader / scene build / 8-wide tree build, and the tile-threaded host path tracer
+    tasks below), concurrent callers of the scene loader / scene build, and the tile-threaded host path tracer
     of the test harness — under ThreadSanitizer: no report, same bytes as single-threaded."""
     from yart_amd import scenes
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")

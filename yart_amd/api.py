@@ -40,7 +40,6 @@ FLAG_NO_REFILL = 16
 FLAG_NO_COMPACTION = 32
 FLAG_NO_SHADE_SORT = 64
 FLAG_NO_RESUME = 128
-FLAG_WIDE_TREES = 256
 FLAG_PATH_POOL = 512
 
 

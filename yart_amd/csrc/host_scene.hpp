@@ -20,7 +20,6 @@
 
 #include "../../include/yart_hip.h"
 #include "bvh_build.hpp"
-#include "bvh8_build.hpp"
 #include "sampler.hpp"
 #include "scene_types.hpp"
 
@@ -37,11 +36,6 @@ struct HostImage {
   std::vector<ShadeTri> shadeTris;
   std::vector<BvhNode> bvhNodes;
   std::vector<LeafTri> leafTris;
-  std::vector<Wide8Node> wideNodes;                // the lean kernels' 8-wide trees (bvh8_build.hpp), every mesh's two trees
-  std::vector<LeafTri> wideTris;
-  bool wideBuilt = false, wideOk = false;          // buildWideTrees has run / every mesh has them (a mesh with non-finite coordinates has not)
-  double wideBuildMs = 0.0;
-  uint32_t wideMaxStack = 0;                       // deepest stack a ray can need in any of the 8-wide trees (Bvh8Builder::maxStack)
   std::vector<u4> triVerts;
   std::vector<int32_t> triLight;
   std::vector<f4> vPos, vNormal, vTangent;
@@ -76,7 +70,6 @@ struct HostImage {
     SceneDev s{};
     s.shadeTris = shadeTris.data();
     s.bvhNodes = bvhNodes.data(); s.leafTris = leafTris.data(); s.triVerts = triVerts.data();
-    s.wideNodes = reinterpret_cast<const uint8_t*>(wideNodes.data()); s.wideTris = wideTris.data();
     s.triLight = triLight.data(); s.vPos = vPos.data(); s.vNormal = vNormal.data();
     s.vTangent = vTangent.data(); s.vUV = vUV.data(); s.meshes = meshes.data(); s.nodes = nodes.data();
     s.materials = materials.data(); s.textures = textures.data(); s.texU8 = texU8.data();
@@ -475,10 +468,6 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
     im.nodeWorld[2 * i] = lo; im.nodeWorld[2 * i + 1] = hi;
   }
 
-  if (im.wideNodes.empty()) im.wideNodes.push_back(Wide8Node{});
-  if (im.wideTris.empty()) im.wideTris.push_back(LeafTri{});
-  for (MeshDev& md : im.meshes) { md.wideRootO = md.wideRootA = kNoWide; md.wideRo = 0.0f; }
-
   // ---- spatial hierarchy over the mesh nodes' padded world boxes (scenes of 64 nodes and more): median splits of the box
   // centres along the widest axis, one node per leaf. Any tree would do: a ray's query only has to return every mesh node whose
   // box it hits (trace_lean_tlas.hpp), the exact tests then run in the reference's pre-order.
@@ -720,103 +709,5 @@ inline CameraDev makeCamera(const YartCameraDesc& c) {
 }
 
 
-// The lean kernels' own structure per mesh (bvh8_build.hpp): an 8-wide tree over the triangles without an alpha-tested material (O)
-// and one over the alpha-tested and the NEE-transparent ones (A), built from the flattened image itself (vertex positions, triangle
-// records, the reference's tree for the acceptance check's leaf boxes). Built on first use (YART_FLAG_WIDE_TREES): the default
-// pipeline walks the reference's tree only. Returns HostImage::wideOk.
-// (tests lower the limit through YART_WIDE_STACK_LIMIT to reach the refusal with a small mesh)
-inline uint32_t wideStackLimit() {
-  if (const char* e = std::getenv("YART_WIDE_STACK_LIMIT")) return uint32_t(std::max(0, std::atoi(e)));
-  return kWideStackDepth;
-}
-inline bool buildWideTrees(HostImage& im) {
-  if (im.wideBuilt) return im.wideOk;
-  im.wideBuilt = true;
-  const auto t0 = std::chrono::high_resolution_clock::now();
-  const uint32_t nn = uint32_t(im.nodes.size());
-  bool ok = nn > 0;
-  double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};
-  for (int c = 0; ok && c < 3; c++) { wlo[c] = (&im.nodeWorld[0].x)[c]; whi[c] = (&im.nodeWorld[1].x)[c]; if (!std::isfinite(wlo[c]) || !std::isfinite(whi[c])) ok = false; }
-  im.wideNodes.clear(); im.wideTris.clear();
-  im.wideNodes.push_back(Wide8Node{});                            // node 0: never a tree's node
-  for (int a = 0; a < 3; a++) for (int s8 = 0; s8 < 8; s8++) im.wideNodes[0].setPlanes(s8, a, kWideGrid, 0);
-  for (uint32_t mi = 0; ok && mi < im.meshes.size(); mi++) {
-    MeshDev& md = im.meshes[mi];
-    md.wideRootO = md.wideRootA = kNoWide; md.wideRo = 0.0f;
-    auto P = [&](uint32_t v) { return &im.vPos[md.vertOffset + v].x; };
-    // |o|_inf bound of the rays that can reach this mesh: the scene's world box seen from every instance, four times over
-    double S = 0.0, Ro = 0.0;
-    for (uint32_t v = 0; v < md.nVerts; v++) for (int c = 0; c < 3; c++) S = std::max(S, std::fabs(double(P(v)[c])));
-    for (uint32_t i = 0; i < nn; i++) {
-      if (im.nodes[i].mesh != int32_t(mi)) continue;
-      uint32_t chain[kMaxNodeDepth]; uint32_t nc = 0;
-      for (int32_t a = int32_t(i); a >= 0 && nc < kMaxNodeDepth; a = im.nodes[a].parent) chain[nc++] = uint32_t(a);
-      for (int corner = 0; corner < 8; corner++) {
-        double p[3] = {(corner & 4) ? whi[0] : wlo[0], (corner & 2) ? whi[1] : wlo[1], (corner & 1) ? whi[2] : wlo[2]};
-        for (uint32_t k = nc; k-- > 0;) {
-          const float* mm = im.nodes[chain[k]].xf.inv;
-          double q[3];
-          for (int r = 0; r < 3; r++) q[r] = double(mm[4 * r]) * p[0] + double(mm[4 * r + 1]) * p[1] + double(mm[4 * r + 2]) * p[2] + double(mm[4 * r + 3]);
-          p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
-        }
-        for (int c = 0; c < 3; c++) Ro = std::max(Ro, std::fabs(p[c]));
-      }
-    }
-    Ro = 4.0 * std::max(Ro, S);
-    if (!std::isfinite(Ro) || !std::isfinite(S) || Ro > 1e15) { ok = false; break; }
-    md.wideRo = float(Ro);
-    const double pad = std::ldexp(16.0 * S + 8.0 * Ro, -24) + 1e-30;
-    std::vector<Bounds3> boxes(md.nTris);
-    std::vector<float> cent(size_t(md.nTris) * 3);
-    std::vector<uint32_t> idsO, idsA;
-    for (uint32_t f = 0; f < md.nTris; f++) {
-      const u4 tv = im.triVerts[md.triOffset + f];
-      const float* pts[3] = {P(tv.x), P(tv.y), P(tv.z)};
-      boxes[f] = boundsFromPoints(pts, 3);
-      for (int c = 0; c < 3; c++) cent[size_t(f) * 3 + c] = 0.5f * (boxes[f].mn[c] + boxes[f].mx[c]);
-      const uint32_t fl = im.materials[tv.w].flags;
-      if (!(fl & MAT_HAS_ALPHA)) idsO.push_back(f);
-      if (fl & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) idsA.push_back(f);
-    }
-    // the reference's leaf of every triangle (scene-wide node index): the box of the acceptance check
-    std::vector<uint32_t> refLeaf(md.nTris, 0);
-    for (uint32_t n = 0; n < md.nNodes; n++) {
-      const BvhNode& bn = im.bvhNodes[md.nodeOffset + n];
-      if (bn.span == 0) continue;
-      for (uint32_t k = 0; k < bn.span; k++) refLeaf[im.bvhIndices[mi][(bn.leftFirst & kLinkIndexMask) + k]] = md.nodeOffset + n;
-    }
-    if (im.bvhNodes.size() >= (size_t(1) << (32 - kWideRefLeafShift))) { ok = false; break; }
-    auto append = [&](const std::vector<uint32_t>& ids, uint32_t& root) {
-      if (ids.empty()) return true;
-      Bvh8Builder b8;
-      if (!b8.build(boxes, cent, ids, pad)) return false;
-      // a tree whose walk could need more stack entries than the kernels' stack (LDS part + spill area: kRefStackDepth in all; the
-      // scalar walk's array likewise) is not used: the scene keeps the walk of the reference's tree (wideOk = false)
-      im.wideMaxStack = std::max(im.wideMaxStack, b8.maxStack);
-      if (b8.maxStack + 2u > kWideStackDepth || b8.maxStack > wideStackLimit()) return false;
-      const uint32_t nodeBase = uint32_t(im.wideNodes.size()), triBase = uint32_t(im.wideTris.size());
-      root = nodeBase;
-      for (Wide8Node w : b8.nodes) { w.childBase += nodeBase; w.triBase += triBase; im.wideNodes.push_back(w); }
-      for (uint32_t t : b8.order) {
-        const u4 tv = im.triVerts[md.triOffset + t];
-        const float *p0 = P(tv.x), *p1 = P(tv.y), *p2 = P(tv.z);
-        LeafTri lt{};
-        for (int c = 0; c < 3; c++) { lt.p0[c] = p0[c]; lt.e1[c] = p1[c] - p0[c]; lt.e2[c] = p2[c] - p0[c]; }
-        lt.triIdx = md.triOffset + t;
-        lt.material = tv.w;
-        lt.matFlags = (im.materials[lt.material].flags & (MAT_HAS_ALPHA | MAT_TRANSPARENT)) | (refLeaf[t] << kWideRefLeafShift);
-        im.wideTris.push_back(lt);
-      }
-      return true;
-    };
-    if (!append(idsO, md.wideRootO) || !append(idsA, md.wideRootA)) { ok = false; break; }
-  }
-  if (im.wideNodes.size() >= (1u << 24)) ok = false;              // (node offsets are 32-bit byte offsets: traverse_wide.hpp)
-  if (!ok) { im.wideNodes.resize(1); im.wideTris.clear(); for (MeshDev& md : im.meshes) md.wideRootO = md.wideRootA = kNoWide; }
-  if (im.wideTris.empty()) im.wideTris.push_back(LeafTri{});
-  im.wideOk = ok;
-  im.wideBuildMs = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
-  return ok;
-}
 
 }  // namespace yart_hip

@@ -102,17 +102,9 @@ struct MeshDev {
   uint32_t vertOffset;     // into vertex arrays
   uint32_t nTris, nVerts, nNodes;
   uint32_t hasAlpha;       // some triangle of the mesh has an alpha-tested material
-  // the lean kernels' own structure (bvh8_build.hpp, trace_lean_wide.inc); indices into SceneDev::wideNodes, scene-wide
-  uint32_t wideRootO;      // root of the 8-wide tree over the triangles without an alpha-tested material; kNoWide: none (mesh not built)
-  uint32_t wideRootA;      // root of the tree over the alpha-tested and the NEE-transparent triangles; kNoWide: the mesh has none
-  float wideRo;            // the trees' boxes are conservative for rays whose object-space origin has |o|_inf <= wideRo
-  uint32_t pad0[5];
+  uint32_t pad0[8];        // (words 8..10 held the roots of rounds 4-5's 8-wide trees: removed, profiles/r5_ab_coop_tree.txt)
 };
 static_assert(sizeof(MeshDev) == 64, "MeshDev is 64 bytes (the lean kernels copy the records into LDS)");
-constexpr uint32_t kNoWide = 0xffffffffu;
-// matFlags word of a WideTri (a LeafTri of the 8-wide trees): bits 0..3 the material flags, bits 4..31 the scene-wide index of the
-// reference's BVH leaf (SceneDev::bvhNodes) that holds the triangle — the box the acceptance check of trace_lean_wide.inc tests
-constexpr uint32_t kWideRefLeafShift = 4;
 
 struct NodeDev {           // core/scene.hpp:11-64
   Xform xf;                // transform (fwd, inv)
@@ -182,8 +174,6 @@ struct SceneDev {
   const ShadeTri* shadeTris;
   const BvhNode* bvhNodes;
   const LeafTri* leafTris;
-  const uint8_t* wideNodes;               // 128-byte nodes of the lean kernels' 8-wide trees (bvh8_build.hpp::Wide8Node)
-  const LeafTri* wideTris;                // their triangle records (same 48 bytes; matFlags: kWideRefLeafShift)
   const u4* triVerts;          // i0, i1, i2 (mesh-local vertex ids), material
   const int32_t* triLight;
   const f4* vPos;              // xyz, pad

@@ -18,7 +18,6 @@
 #pragma once
 #if defined(__HIPCC__)
 #include "traverse.hpp"
-#include "traverse_wide.hpp"
 
 namespace yart_hip {
 
@@ -34,16 +33,6 @@ constexpr uint32_t kLeanRefill = YART_LEAN_REFILL;      // refill when at least 
 #define YART_LEAN_INNER_MIN 12
 #endif
 constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;
-// the same two thresholds for the kernels that walk their own 8-wide trees (a node step there is twice a binary step)
-#ifndef YART_WIDE_REFILL
-#define YART_WIDE_REFILL 52
-#endif
-#ifndef YART_WIDE_INNER_MIN
-#define YART_WIDE_INNER_MIN 12
-#endif
-#ifndef YART_WIDE_TRI_MIN
-#define YART_WIDE_TRI_MIN 8      // the triangle loop is left when fewer lanes than this still have triangles and others wait to step
-#endif
 #ifndef YART_LEAN_CHUNK_MAX
 #define YART_LEAN_CHUNK_MAX 256u
 #endif   // leave the inner loop when fewer lanes than this still step
@@ -84,14 +73,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                                           uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
                                           Retry retry, WfTally& tally) {
   constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
-  // TRAV_WIDE (lean kernels only): inside a mesh the ray is walked through the mesh's own 8-wide trees by a group of eight lanes
-  // (trace_lean_coop.inc) instead of through the reference's binary tree by its own lane; rays whose result could depend on the
-  // reference's order go to the general kernel (from the root)
-  constexpr bool kWide = (MODE & TRAV_WIDE) != 0;
-  static_assert(!kWide || kFast, "TRAV_WIDE is a variant of the lean (TRAV_FAST) walk");
-  constexpr uint32_t kRefill = kWide ? uint32_t(YART_WIDE_REFILL) : kLeanRefill;      // (the names the parts below use)
-  uint32_t wRootA = kNoWide, wRootO = kNoWide;                // the current mesh's trees (kWide)
-  bool crossedT = false;                                      // shadow ray: crossed an NEE-transparent triangle while unoccluded
+  constexpr uint32_t kRefill = kLeanRefill;
   Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
   f3 attenuation = mk3(1.0f);
   const uint32_t lane = threadIdx.x & 63u;
@@ -131,7 +113,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
       // such repeats, profiles/r3_ab_top_cache.txt). Not for a shadow ray that is occluded already: from then on the lean walk
       // skips subtrees without alpha-tested triangles, which the general walk — the reference's — does not.
       uint32_t word = slot;
-      if (!kWide && stk.rec != nullptr && __ballot(pendingRetry) != 0ull) {
+      if (stk.rec != nullptr && __ballot(pendingRetry) != 0ull) {
         const bool can = pendingRetry && stackIdx <= kResumeStack && !(NEE && (didHit || meshDidHit));
         const unsigned long long mc = __ballot(can);
         const uint32_t need = uint32_t(__popcll(mc));
@@ -210,7 +192,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
           const LeanRay r = fetch(slot);
           ray = makeRay(r.o + 0.0f, r.d + 0.0f); rayIsWorld = true;
           hit.t = r.tMax; hit.u = hit.v = 0; hit.tri = 0; hit.node = 0; hit.backSide = 0;
-          has = true; inMesh = false; nodeI = 0; didHit = false; crossedT = false;
+          has = true; inMesh = false; nodeI = 0; didHit = false;
           if (!kFast) { smp = r.smp; attenuation = mk3(1.0f); }
           YART_COUNT(nTrav, 1);
 #if defined(YART_COUNT_TRAVERSAL)
@@ -277,10 +259,7 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
         WF_PHASE(tally, 3);                                     // walk steps
         const unsigned long long rest = nodeI < 64u ? (cand >> nodeI) : 0ull;
         if (rest == 0ull) {                                     // testNode of the root has returned
-          // (wide walk, shadow ray: an unoccluded ray that crossed an NEE-transparent triangle carries an attenuation the
-          // reference multiplies up in its order: the general kernel's)
-          if (kWide && NEE && crossedT && !didHit) pendingRetry = true;
-          else done = true;                                     // (committed at the next refill)
+          done = true;                                          // (committed at the next refill)
           has = false;
         } else {
           nodeI += uint32_t(__builtin_ctzll(rest));             // next node the ray can reach
@@ -312,16 +291,8 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                 const BvhNode root = nodes[0];
                 YART_COUNT(nBox, 1);
                 if (testBox(ray, tMin, hit.t, root.bmin, root.bmax, d)) {     // testBVH entry
-                  if (kWide) {
-                    // tree A (alpha-tested / NEE-transparent triangles) first, then tree O: walked by a group of eight lanes in part (C)
-                    WideSetup guard;
-                    if (!wideSetup(ray, mesh.wideRo, guard)) { YART_COUNT(nHand[3], 1); pendingRetry = true; has = false; }
-                    else { inMesh = true; meshDidHit = false; stackIdx = 0; wRootA = mesh.wideRootA; wRootO = mesh.wideRootO; }
-                    entered = true;
-                  } else {
                   inMesh = true; entered = true;
                   leftFirst = root.leftFirst; span = root.span; stackIdx = 0; meshDidHit = false;
-                  }
                 }
               }
             }
@@ -331,18 +302,12 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
       }
     }
 
-    if constexpr (kWide) {
-#include "trace_lean_coop.inc"
-    } else {
 #include "trace_lean_bvh2.inc"
-    }
   }
 #undef LEAN_VISIT
   (void)meshHasAlpha;
 #if defined(YART_COUNT_TRAVERSAL)
   tally.box += actx.nBox; tally.tri += actx.nTri; tally.trav += actx.nTrav; tally.resumed += actx.nResumed;
-  tally.wideNodes += actx.nWideNodes; tally.wideTris += actx.nWideTris;
-  for (int k = 0; k < 4; k++) tally.hand[k] += actx.nHand[k];
 #else
   (void)tally;
 #endif

@@ -71,15 +71,9 @@ YART_HD void testBox2(const RayO& r, float tIntMin, float tIntMax, const BvhNode
 // every pop into a flat_load with a full vmcnt+lgkmcnt wait).
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
 #else
 typedef uint64_t lds_u64;
-typedef uint32_t lds_u32;
 #endif
-// LDS of the lane-cooperative walk of the 8-wide trees (trace_lean_coop.inc), per wave: one record per lane's published ray
-// (object-space ray, interval, tree roots in; hit record and status out) and one stack per group of eight lanes.
-constexpr uint32_t kCoopRecWords = 20, kCoopStackDepth = 32;
-constexpr uint32_t kCoopWaveWords = 64u * kCoopRecWords + 8u * kCoopStackDepth * 2u;      // 1792 words = 7 KB per wave
 // Walks the lean kernels hand to the general ones are RESUMED, not restarted (trace_lean.hpp): one record per handed-over ray.
 //   word 0: path slot, scene node, flags (bit 0 didHit, bit 1 meshDidHit, bits 8.. stack entries), link word of the leaf
 //   word 1: the leaf's entry distance, hit.t, candidate mask      word 2 (closest-hit rays that have a hit): hit.u, hit.v, hit.tri,
@@ -92,7 +86,6 @@ struct TravStack {
   uint64_t* spill; uint32_t spillStride;
   // resume records of this launch (null: every hand-over is a restart): written by the lean kernels, read by the general ones
   f4* rec = nullptr; uint32_t* recCursor = nullptr; uint32_t recCap = 0;
-  lds_u32* coop = nullptr;     // TRAV_WIDE kernels: this WAVE's kCoopWaveWords words of LDS (trace_lean_coop.inc)
 };
 YART_HD void stackPush(const TravStack& s, uint32_t k, uint32_t node, float d) {
   uint32_t db = __builtin_bit_cast(uint32_t, d);
@@ -141,9 +134,7 @@ struct HitRec {              // what the walk tracks of cpu/hit.hpp
 //   TRAV_IDENTITY  every scene node's transform chain is the identity (checked at scene build):
 //                  no 4x4 products, the world ray (+0) is used for every node; ~30 VGPRs.
 // Together they bring the closest-hit kernel from 127 to 74 VGPRs, i.e. from 4 to 6 waves/SIMD.
-//   TRAV_WIDE      lean kernels with in-wave replacement only (trace_lean.hpp): inside a mesh the ray walks the mesh's own
-//                  8-wide trees (bvh8_build.hpp, trace_lean_wide.inc) instead of the reference's binary tree.
-enum : int { TRAV_GENERAL = 0, TRAV_FAST = 1, TRAV_IDENTITY = 2, TRAV_WIDE = 4 };
+enum : int { TRAV_GENERAL = 0, TRAV_FAST = 1, TRAV_IDENTITY = 2 };
 
 struct AlphaCtx {            // state the stochastic alpha test draws from
   Sampler* sampler;
@@ -151,8 +142,6 @@ struct AlphaCtx {            // state the stochastic alpha test draws from
   bool deferred = false;     // TRAV_FAST: the ray met an alpha / transparent candidate
 #if defined(YART_COUNT_TRAVERSAL)
   uint32_t nBox = 0, nTri = 0, nTrav = 0, nResumed = 0;
-  uint32_t nWideNodes = 0, nWideTris = 0;     // node visits / triangle tests of the 8-wide walk
-  uint32_t nHand[4] = {0, 0, 0, 0};           // its hand-overs: alpha / transparent crossing, tie, acceptance check (or NaN t), ray guard
 #endif
 };
 

@@ -32,7 +32,6 @@ struct WfTally {
   uint32_t box = 0, tri = 0, trav = 0, shade = 0;
   uint32_t resumed = 0;        // handed-over rays the general kernels took up where the lean kernel stood
   uint32_t waste = 0;          // box tests the lean kernels spent on rays they then handed to the general kernels
-  uint32_t wideNodes = 0, wideTris = 0, hand[4] = {0, 0, 0, 0};   // the 8-wide walk (traverse.hpp::AlphaCtx)
 #endif
 #if defined(YART_TRACE_STATS)
   // debug build: wave-iteration / active-lane counts per phase of the wave tracer

@@ -53,7 +53,6 @@ constexpr int kSpillDepthMax = int(kRefStackDepth);   // spill area sized for th
 constexpr uint64_t kDefaultBatchPaths = 1ull << 28;   // YartRenderParams::max_batch_paths = 0: 268 M paths (batch-synchronous: 77 GB; path pool: 4.3 GB of per-sample records)
 constexpr uint64_t kDefaultPoolPaths = 1ull << 25;    // YartRenderParams::pool_paths = 0: 33.5 M slots, 5.6 GB
 constexpr int kPoolLag = 4;                            // the host looks at the counters of the round before the previous one (ring of 4)
-static_assert(kWideStackDepth == kRefStackDepth, "bvh8_build.hpp bounds its trees by the stack the walks hold (traverse.hpp)");
 constexpr int kNumCounters = 32;       // [0] rays, [1..4] instrumented tallies, [8..31] debug statistics
 
 thread_local std::string g_lastError;
@@ -356,7 +355,7 @@ struct YartScene {
   int numCUs = 256;
   bool texQuadsOn = true;      // the textures' 2x2 footprint records are on the device (uploadScene: they fit the budget)
   // device copies of the scene image
-  DevBuf<f4> resumeRec; DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<Wide8Node> wideNodes; DevBuf<LeafTri> wideTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
+  DevBuf<f4> resumeRec; DevBuf<ShadeTri> shadeTris; DevBuf<BvhNode> bvhNodes; DevBuf<LeafTri> leafTris; DevBuf<u4> triVerts; DevBuf<int32_t> triLight;
   DevBuf<f4> vPos, vNormal, vTangent; DevBuf<f2> vUV; DevBuf<MeshDev> meshes; DevBuf<NodeDev> nodes;
   DevBuf<MaterialDev> materials; DevBuf<TexDev> textures; DevBuf<uint8_t> texU8; DevBuf<float> texF32; DevBuf<uint8_t> texQuads;
   DevBuf<LightDev> lights; DevBuf<EnvDev> envs; DevBuf<float> envData; DevBuf<uint32_t> envGuide; DevBuf<f4> nodeWorld; DevBuf<TlasNode> tlas; DevBuf<unsigned long long> nodeBits;
@@ -391,7 +390,6 @@ void uploadScene(YartScene& s) {
   const HostImage& h = s.host;
   s.shadeTris.upload(h.shadeTris);
   s.bvhNodes.upload(h.bvhNodes); s.leafTris.upload(h.leafTris); s.triVerts.upload(h.triVerts);
-  s.wideNodes.upload(h.wideNodes); s.wideTris.upload(h.wideTris);
   s.triLight.upload(h.triLight); s.vPos.upload(h.vPos); s.vNormal.upload(h.vNormal);
   s.vTangent.upload(h.vTangent); s.vUV.upload(h.vUV); s.meshes.upload(h.meshes); s.nodes.upload(h.nodes);
   s.materials.upload(h.materials); s.textures.upload(h.textures); s.texU8.upload(h.texU8);
@@ -428,7 +426,6 @@ void uploadScene(YartScene& s) {
   SceneDev d = h.view();       // counts and totals; pointers replaced below
   d.shadeTris = s.shadeTris.p;
   d.bvhNodes = s.bvhNodes.p; d.leafTris = s.leafTris.p; d.triVerts = s.triVerts.p; d.triLight = s.triLight.p;
-  d.wideNodes = reinterpret_cast<const uint8_t*>(s.wideNodes.p); d.wideTris = s.wideTris.p;
   d.vPos = s.vPos.p; d.vNormal = s.vNormal.p; d.vTangent = s.vTangent.p; d.vUV = s.vUV.p;
   d.meshes = s.meshes.p; d.nodes = s.nodes.p; d.materials = s.materials.p; d.textures = s.textures.p;
   d.texU8 = s.texU8.p; d.texF32 = s.texF32.p; d.texQuads = s.texQuadsOn ? s.texQuads.p : nullptr; d.lights = s.lights.p; d.envs = s.envs.p;
@@ -613,18 +610,6 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const bool tlasOk = s.dev.nTlas != 0u && s.host.nodes.size() <= 16384u && !(effFlags & (262144u | 65536u));
   const bool leanLds = !chunked && s.host.nodes.size() <= kLeanSceneNodes && s.host.meshes.size() <= kLeanSceneNodes;
   const int nodesForm = !chunked ? (leanLds ? 4 : 0) : tlasOk ? 3 : ((effFlags & 65536u) || s.host.nodes.size() >= kLeanWalkNodes) ? 2 : 1;
-  // YART_FLAG_WIDE_TREES: the lean kernels walk their own 8-wide trees (trace_lean_wide.inc); scenes of fewer than 64 nodes whose
-  // meshes all have them (measured slower than the walk of the reference's tree on both bench scenes: DESIGN §4b — not the default)
-  bool wide = (p.flags & YART_FLAG_WIDE_TREES) && !chunked && refill && !general;
-  if (wide && !s.host.wideBuilt) {
-    // built on first use, from the flattened scene image; the mesh records carry the trees' roots
-    if (buildWideTrees(s.host)) {
-      s.wideNodes.upload(s.host.wideNodes); s.wideTris.upload(s.host.wideTris); s.meshes.upload(s.host.meshes);
-      s.dev.wideNodes = reinterpret_cast<const uint8_t*>(s.wideNodes.p); s.dev.wideTris = s.wideTris.p; s.dev.meshes = s.meshes.p;
-    }
-  }
-  wide = wide && s.host.wideOk;
-  if (!wide) effFlags &= ~YART_FLAG_WIDE_TREES;
 #define YART_PICK_LEAN(KERNEL, M)                                                                                             \
   (nodesForm == 4 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 4> : KERNEL<(M), 4>)                                                 \
    : nodesForm == 3 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 3> : KERNEL<(M), 3>)                                               \
@@ -632,14 +617,10 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
    : nodesForm == 1 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 1> : KERNEL<(M), 1>) : (ident ? KERNEL<(M) | TRAV_IDENTITY, 0> : KERNEL<(M), 0>))
   auto pickExtend = [&]() -> void (*)(WfArgs) {
     if (!refill) return ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
-    if (wide) return nodesForm == 4 ? (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_WIDE | TRAV_IDENTITY, 4> : k_wf_extend_lean<TRAV_FAST | TRAV_WIDE, 4>)
-                                    : (ident ? k_wf_extend_lean<TRAV_FAST | TRAV_WIDE | TRAV_IDENTITY, 0> : k_wf_extend_lean<TRAV_FAST | TRAV_WIDE, 0>);
     return YART_PICK_LEAN(k_wf_extend_lean, TRAV_FAST);
   };
   auto pickShadow = [&]() -> void (*)(WfArgs) {
     if (!refill) return ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>;
-    if (wide) return nodesForm == 4 ? (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE | TRAV_IDENTITY, 4> : k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE, 4>)
-                                    : (ident ? k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE | TRAV_IDENTITY, 0> : k_wf_shadow_lean<TRAV_FAST | TRAV_WIDE, 0>);
     return YART_PICK_LEAN(k_wf_shadow_lean, TRAV_FAST);
   };
 #undef YART_PICK_LEAN
@@ -1052,8 +1033,6 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     stats->ms_shadow_lean = tShadowLean.ms; stats->launches_shadow_lean = tShadowLean.launches;
     stats->shadow_lean_traversals = cnt[24]; stats->shadow_lean_box_tests = cnt[25]; stats->shadow_lean_tri_tests = cnt[26];
     stats->shade_entries = cnt[28]; stats->retry_extend_traversals = cnt[29]; stats->retry_shadow_traversals = cnt[30];
-    stats->wide_extend_nodes = cnt[10]; stats->wide_extend_tris = cnt[11]; stats->wide_shadow_nodes = cnt[12]; stats->wide_shadow_tris = cnt[13];
-    for (int k = 0; k < 4; k++) { stats->wide_extend_handed[k] = cnt[14 + k]; stats->wide_shadow_handed[k] = cnt[18 + k]; }
     stats->pipeline_flags = effFlags;
     {
       unsigned long long pl[16] = {0};

@@ -722,28 +722,6 @@ def stacked_leaves(width=96, height=96, spp=4, depth=4, stacks=(40, 32, 64, 31, 
     return s, p
 
 
-def geometric_spine(width=48, height=48, spp=2, depth=4, clusters=150, ratio=1.35):
-    """Cornell room + a spine of small cards whose positions and sizes grow geometrically along +x: a SAH build
-    peels one cluster off at a time, so any tree over it is as deep as it has clusters — the shape that bounds how deep a
-    traversal stack can get. The lean kernels' 8-wide trees are refused for such a mesh when their walk could need more stack
-    entries than the kernels hold (bvh8_build.hpp::maxStack, host_scene.hpp::buildWideTrees)."""
-    s, p = cornell(width, height, spp, depth)
-    m = s.add_material(Material(base=(0.7, 0.7, 0.2), roughness=0.6))
-    b = MeshBuilder()
-    x = 1e-6
-    for k in range(clusters):
-        e = 0.2 * x
-        for j in range(3):                                  # three cards per cluster, fanned
-            y0 = 2.0 + e * j
-            b.quad((x, y0, -1.0), (x + e, y0, -1.0), (x + e, y0 + e, -1.0 + e * 0.1 * j), (x, y0 + e, -1.0), m)
-        x *= ratio
-        if x > 4.0:
-            x = 1e-6 * (1.0 + 0.37 * k)
-    s.add_node(s.add_mesh(b.build()))
-    s.create_area_lights()
-    return s, p
-
-
 def random_scene(seed, width=64, height=48, spp=4, depth=6, crowd=0, extras=False):
     """Seeded random scene of the parity fuzz (tests/test_fuzz_scenes.py): every constructor argument of the reference's
     ParametricBSDF (bsdf/parametric.hpp:16-37) drawn at random — with the end points 0 and 1 over-represented, they pick other

@@ -296,6 +296,13 @@ int yart_hip_multi_create(const YartSceneDesc* desc, const int* devices, uint32_
 int yart_hip_multi_load(const char* path, const YartImportOptions* opts, const int* devices, uint32_t n_devices, YartMulti** out);
 void yart_hip_multi_destroy(YartMulti* multi);
 int yart_hip_multi_device_count(const YartMulti* multi);
+/* Failure of a device (SURVEY §5 "failure detection"; the reference has none: a worker thread that dies takes the process along). A
+ * HIP error on the host thread of a replica other than devices[0] takes THAT replica out of service for the rest of the handle's life:
+ * the call still succeeds — the replica's pixel blocks are rendered on devices[0] after the merge (blocks are idempotent: which
+ * device renders a pixel does not change it), in this and in every later render. This entry point reports the replicas out of service
+ * (indices into the `devices` list, at most `capacity` written; returns their number) and leaves the first failure's message in
+ * yart_hip_last_error(). A failure of devices[0] itself, where the frame is merged, is the call's error (YART_E_HIP). */
+int yart_hip_multi_failed_devices(const YartMulti* multi, int* replicas_out, uint32_t capacity);
 /* Diagnostic: the RCCL calls of the merge (ncclCommInitAll, one group of ncclSend + ncclRecv on a stream, ncclCommDestroy) on a
  * one-rank communicator of `device` — the rank sends a slab of n_floats to itself and compares. Shows on a one-GPU box that
  * RCCL is linked, initialises and moves a slab; YART_E_RCCL otherwise. */

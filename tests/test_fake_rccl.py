@@ -63,22 +63,30 @@ for k in range({renders}):
     try:
         img, st = m.render(p)
         res["steps"].append({{"ok": True, "identical": bool(np.array_equal(img.view(np.uint32), ref.view(np.uint32))),
-                             "rays": int(st["rays"]), "rays_single": int(st0["rays"])}})
+                             "rays": int(st["rays"]), "rays_single": int(st0["rays"]), "samples": int(st["samples"]),
+                             "samples_single": int(st0["samples"]), "failed": m.failed_replicas()}})
     except api.YartError as e:
         res["steps"].append({{"ok": False, "code": e.code, "message": str(e)}})
+if {tiles}:
+    seen = []
+    img, st, _ = m.render_tiles(p, on_tile=lambda frame, t: seen.append((t["x"], t["y"], t["width"], t["height"], t["rays"], t["wave"])) and None)
+    res["tiles"] = {{"identical": bool(np.array_equal(img.view(np.uint32), ref.view(np.uint32))), "n": len(seen),
+                    "rays": sum(t[4] for t in seen), "rays_single": int(st0["rays"]), "distinct": len(set(t[:4] + (t[5],) for t in seen))}}
 m.close()
 print(json.dumps(res))
 """
 
 
-def _run(fake, tmp_path, devices=(0, 0, 0), renders=1, fail=None, assume=True, case="cornell_waves"):
+def _run(fake, tmp_path, devices=(0, 0, 0), renders=1, fail=None, assume=True, case="cornell_waves", fault=None, tiles=False):
     log = str(tmp_path / "rccl.log")
     env = dict(os.environ, YART_RCCL_LIB=fake, FAKE_RCCL_LOG=log)
+    if fault is not None:
+        env["YART_FAULT_REPLICA"], env["YART_FAULT_AT"] = str(fault[0]), str(fault[1])
     if assume:
         env["YART_MULTI_ASSUME_DISTINCT"] = "1"
     if fail:
         env["FAKE_RCCL_FAIL_FN"], env["FAKE_RCCL_FAIL_CALL"] = fail[0], str(fail[1])
-    code = CHILD.format(root=ROOT, base=os.path.join(GOLDEN, case), devices=list(devices), renders=renders)
+    code = CHILD.format(root=ROOT, base=os.path.join(GOLDEN, case), devices=list(devices), renders=renders, tiles=bool(tiles))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)   # (a hang fails here)
     assert r.returncode == 0, r.stderr[-2000:]
     calls = open(log).read().splitlines() if os.path.exists(log) else []
@@ -148,3 +156,34 @@ def test_repeated_devices_without_the_override_use_peer_copies(fake_rccl, tmp_pa
 def test_named_library_that_cannot_be_loaded_is_an_error(tmp_path):
     res, _ = _run(str(tmp_path / "no_such_librccl.so"), tmp_path)
     assert res.get("create_error", [0])[0] == YART_E_RCCL and "YART_RCCL_LIB" in res["create_error"][1], res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["rccl stand-in", "peer copies"])
+@pytest.mark.parametrize("replica,at", [(1, 0), (2, 1)])
+def test_failed_device_is_taken_out_of_service_and_its_blocks_requeued(fake_rccl, tmp_path, transport, replica, at):
+    """SURVEY §5 "failure detection": per-GPU failure = re-queue that GPU's tiles (they are idempotent). A HIP error on the thread of
+    replica 1 or 2 (injected: YART_FAULT_REPLICA / YART_FAULT_AT, at the first or the second render of the handle) does not fail the
+    call: the replica is out of service from then on, its pixel blocks are rendered on devices[0] after the merge — through the
+    RCCL branch (the failed rank posts no send and gets no receive) and through the one-device transport alike — and every frame,
+    ray count and sample count stays the single device's; the tile callbacks still report every block of the frame once per wave
+    with its own ray count."""
+    res, calls = _run(fake_rccl, tmp_path, renders=3, assume=(transport == "rccl stand-in"), fault=(replica, at), tiles=True)
+    assert len(res["steps"]) == 3
+    for k, s in enumerate(res["steps"]):
+        assert s["ok"] and s["identical"] and s["rays"] == s["rays_single"] and s["samples"] == s["samples_single"], (k, s)
+        assert s["failed"] == ([replica] if k >= at else []), (k, s)
+    t = res["tiles"]
+    assert t["identical"] and t["rays"] == t["rays_single"] and t["n"] == t["distinct"] == 16 * 2, t     # 16 blocks x 2 waves
+    if transport == "rccl stand-in":
+        ends = [c for c in calls if c.startswith("ncclGroupEnd")]
+        assert all("unmatched=0" in c and "rc=0" in c for c in ends), ends
+        assert [("matched_pairs=2" in c) for c in ends][:at] == [True] * at              # both remote ranks before the failure,
+        assert all("matched_pairs=1" in c for c in ends[at:]), ends                       # one afterwards
+        assert not any(c.startswith("ncclCommAbort") for c in calls)
+
+
+@pytest.mark.gpu
+def test_failure_of_the_merge_device_is_the_calls_error(fake_rccl, tmp_path):
+    res, _ = _run(fake_rccl, tmp_path, renders=1, fault=(0, 0))
+    assert not res["steps"][0]["ok"] and res["steps"][0]["code"] == -3, res            # YART_E_HIP

@@ -193,7 +193,7 @@ EXPORTS = ["yart_hip_abi_version", "yart_hip_device_count", "yart_hip_last_error
            "yart_hip_render", "yart_hip_render_waves", "yart_hip_render_tiles", "yart_hip_render_device", "yart_hip_probe_samples",
            "yart_hip_probe_hits", "yart_hip_probe_sampler", "yart_hip_bvh_info", "yart_hip_bvh_copy", "yart_hip_scene_create_flags", "yart_hip_bvh_build_device", "yart_hip_bvh_build_host", "yart_hip_debug_counters", "yart_hip_debug_shade_regions",
            "yart_hip_tonemap_agx", "yart_hip_encode_rgb8", "yart_hip_tonemap_host",
-           "yart_hip_multi_create", "yart_hip_multi_load", "yart_hip_multi_destroy", "yart_hip_multi_device_count",
+           "yart_hip_multi_create", "yart_hip_multi_load", "yart_hip_multi_destroy", "yart_hip_multi_device_count", "yart_hip_multi_failed_devices",
            "yart_hip_multi_render", "yart_hip_multi_render_tiles", "yart_hip_multi_rccl_selftest"]
 
 LIB_COUNT_PATH = os.path.join(_HERE, "libyart_hip_count.so")   # instrumented twin (exact test counters)
@@ -525,6 +525,13 @@ class MultiDeviceScene:
     @property
     def n_devices(self):
         return int(self._L.yart_hip_multi_device_count(self._h))
+
+    def failed_replicas(self):
+        """Replicas taken out of service by a device failure (their blocks are rendered on devices[0]); [] normally."""
+        out = (C.c_int * 64)()
+        self._L.yart_hip_multi_failed_devices.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        n = int(self._L.yart_hip_multi_failed_devices(self._h, out, 64))
+        return [int(out[k]) for k in range(min(n, 64))]
 
     def render(self, p: dict, rank=0, world_size=1, flags=0, accumulated=None):
         cam, rp, st = make_camera(p), make_params(p, rank, world_size, flags), Stats()

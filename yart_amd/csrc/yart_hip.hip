@@ -1315,6 +1315,15 @@ int yart_hip_multi_rccl_selftest(int device, uint32_t n_floats) {
 
 int yart_hip_multi_device_count(const YartMulti* multi) { return multi ? int(multi->scenes.size()) : 0; }
 
+int yart_hip_multi_failed_devices(const YartMulti* multi, int* replicas_out, uint32_t capacity) {
+  if (!multi) return 0;
+  int nf = 0;
+  for (size_t i = 0; i < multi->failed.size(); i++)
+    if (multi->failed[i]) { if (replicas_out && uint32_t(nf) < capacity) replicas_out[nf] = int(i); nf++; }
+  if (nf) g_lastError = multi->failureNote;
+  return nf;
+}
+
 int yart_hip_multi_render(YartMulti* multi, const YartCameraDesc* cam, const YartRenderParams* params, float* out_rgba,
                           YartStats* stats) {
   return guarded([&] {

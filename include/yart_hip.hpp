@@ -93,6 +93,14 @@ class MultiDeviceScene {
   MultiDeviceScene& operator=(const MultiDeviceScene&) = delete;
   ~MultiDeviceScene() { yart_hip_multi_destroy(h_); }
   YartMulti* handle() const { return h_; }
+  int deviceCount() const { return yart_hip_multi_device_count(h_); }
+  // replicas a device failure took out of service (their pixel blocks are rendered on the first device from then on); empty normally
+  std::vector<int> failedReplicas() const {
+    std::vector<int> out(64);
+    const int n = yart_hip_multi_failed_devices(h_, out.data(), uint32_t(out.size()));
+    out.resize(size_t(n < 64 ? n : 64));
+    return out;
+  }
 
  private:
   YartMulti* h_ = nullptr;

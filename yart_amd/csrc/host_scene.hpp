@@ -595,7 +595,12 @@ inline HostImage buildHostImage(const YartSceneDesc& d, MeshBvhFn bvhFn = nullpt
             im.envGuide.push_back(idx);
           }
         };
-        e.guideKw = pow2ge(w); e.guideKh = pow2ge(h);
+        // K = 4 n: a cell of the guide then rarely holds a breakpoint, and the search that follows is mostly zero or one step —
+        // a wave pays the LONGEST search of its 64 lanes (profiles/r5_shade_env_search.txt: shade kernel -1.7 % against K = n for 50 MB
+        // of tables at 2048^2; K = 16 n: -2.4 % for 250 MB). YART_ENV_GUIDE_MUL overrides (measurements).
+        uint32_t mul = 4;
+        if (const char* g = std::getenv("YART_ENV_GUIDE_MUL")) mul = uint32_t(std::max(1, std::min(16, std::atoi(g))));
+        e.guideKw = pow2ge(w) * mul; e.guideKh = pow2ge(h) * mul;
         e.guideOffset = uint32_t(im.envGuide.size());
         appendGuide(im.envData.data() + e.margCdfOffset, h, e.guideKh);
         for (uint32_t y = 0; y < h; y++) appendGuide(im.envData.data() + e.cdfOffset + size_t(y) * (w + 1), w, e.guideKw);

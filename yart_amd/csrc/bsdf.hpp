@@ -18,7 +18,7 @@ struct TexTaps { uint32_t i00, i01, i10, i11; float u, v; };
 // Instrumented build (libyart_hip_count.so) only: bytes of texel data the lookups of one render need —
 // 4 taps x channels x (1 B | 4 B) per lookup, SURVEY §8(d)'s "4·C·taps" term of B_shade — summed per wave.
 #if defined(YART_COUNT_TRAVERSAL) && defined(__HIPCC__)
-__device__ unsigned long long g_texTapBytes;
+static __device__ unsigned long long g_texTapBytes;     // (one per translation unit: yart_hip.hip sums its units')
 #endif
 #if defined(YART_COUNT_TRAVERSAL) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void texTally(const TexDev& t) {

@@ -64,7 +64,7 @@ struct WfTally {
 // in LDS, so no registers are taken from the kernel) and counts the lanes that ran it. Empty otherwise.
 #if defined(YART_SHADE_REGIONS) && defined(__HIPCC__)
 constexpr int kShadeRegions = 16;
-__device__ unsigned long long g_shadeRegion[3 * kShadeRegions];   // [k] cycles, [16 + k] visits, [32 + k] lanes
+static __device__ unsigned long long g_shadeRegion[3 * kShadeRegions];   // [k] cycles, [16 + k] visits, [32 + k] lanes
 #endif
 #if defined(YART_SHADE_REGIONS) && defined(__HIP_DEVICE_COMPILE__)
 __shared__ unsigned long long srAcc[16][3 * kShadeRegions];    // (one row per wave of the workgroup: the shade kernel runs 12)

@@ -14,6 +14,15 @@
 //                   blend into the HDR buffer (integrator.cpp:17-25, tile-renderer.hpp:220-232).
 //   k_probe_*       diagnostics used by the parity tests.
 // The wavefront (queue-based) pipeline lives in wavefront.hip.inc.
+// This file is compiled four times (csrc/Makefile), YART_TU selecting what a translation unit emits — the kernels are templates and
+// instantiate where they are referenced, so the four objects build in parallel and each holds a quarter of the device code:
+//   0  the C ABI, host orchestration, and every kernel not named below (streaming passes, megakernel, probes, BVH build)
+//   1  the lean closest-hit kernels k_wf_extend_lean<MODE, NODES>          2  the lean any-hit kernels k_wf_shadow_lean<MODE, NODES>
+//   3  the general kernels: retry (resumed walks), one-ray-per-lane lean and general forms        4  the shade kernel k_wf_shade<SORT, FIT, ENV1>
+// Units 1-4 export their kernels as type-erased host stubs (yart_hip::tu::*, below); unit 0 launches them through those pointers.
+#ifndef YART_TU
+#define YART_TU 0
+#endif
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -89,6 +98,7 @@ struct DevBuf {
 // ---------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------
+#if YART_TU == 0
 struct MegaArgs {
   SceneDev sc;
   CameraDev cam;
@@ -334,8 +344,92 @@ __global__ void __launch_bounds__(kBlock) k_tex_quads(TexQuadArgs a) {
   }
 }
 
+#endif  // YART_TU == 0
+
 #include "wavefront_kernels.inc"
+#if YART_TU == 0
 #include "bvh_build_device.inc"
+#endif
+
+#if YART_TU != 0
+}  // namespace
+
+// the kernels of this unit, for unit 0 (function pointers to the host stubs; the argument type is the same struct in every unit)
+namespace yart_hip { namespace tu {
+typedef void (*AnyKernel)();
+#define YART_ANY(K) reinterpret_cast<AnyKernel>(static_cast<void (*)(WfArgs)>(K))
+#define YART_PICK_LEAN(KERNEL, M)                                                                                             \
+  (nodesForm == 4 ? (ident ? YART_ANY((KERNEL<(M) | TRAV_IDENTITY, 4>)) : YART_ANY((KERNEL<(M), 4>)))                         \
+   : nodesForm == 3 ? (ident ? YART_ANY((KERNEL<(M) | TRAV_IDENTITY, 3>)) : YART_ANY((KERNEL<(M), 3>)))                       \
+   : nodesForm == 2 ? (ident ? YART_ANY((KERNEL<(M) | TRAV_IDENTITY, 2>)) : YART_ANY((KERNEL<(M), 2>)))                       \
+   : nodesForm == 1 ? (ident ? YART_ANY((KERNEL<(M) | TRAV_IDENTITY, 1>)) : YART_ANY((KERNEL<(M), 1>)))                       \
+                    : (ident ? YART_ANY((KERNEL<(M) | TRAV_IDENTITY, 0>)) : YART_ANY((KERNEL<(M), 0>))))
+#if YART_TU == 1
+AnyKernel extendLean(int nodesForm, bool ident) { return YART_PICK_LEAN(k_wf_extend_lean, TRAV_FAST); }
+#elif YART_TU == 2
+AnyKernel shadowLean(int nodesForm, bool ident) { return YART_PICK_LEAN(k_wf_shadow_lean, TRAV_FAST); }
+#elif YART_TU == 3
+AnyKernel extendRetry(int nodesForm) {
+  return nodesForm == 4 ? YART_ANY(k_wf_extend_retry_lean<4>) : nodesForm == 3 ? YART_ANY(k_wf_extend_retry_lean<3>)
+       : nodesForm == 2 ? YART_ANY(k_wf_extend_retry_lean<2>) : nodesForm == 1 ? YART_ANY(k_wf_extend_retry_lean<1>) : YART_ANY(k_wf_extend_retry_lean<0>);
+}
+AnyKernel shadowRetry(int nodesForm) {
+  return nodesForm == 4 ? YART_ANY(k_wf_shadow_retry_lean<4>) : nodesForm == 3 ? YART_ANY(k_wf_shadow_retry_lean<3>)
+       : nodesForm == 2 ? YART_ANY(k_wf_shadow_retry_lean<2>) : nodesForm == 1 ? YART_ANY(k_wf_shadow_retry_lean<1>) : YART_ANY(k_wf_shadow_retry_lean<0>);
+}
+AnyKernel extendFast(bool ident) { return ident ? YART_ANY((k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY>)) : YART_ANY(k_wf_extend_fast<TRAV_FAST>); }
+AnyKernel shadowFast(bool ident) { return ident ? YART_ANY((k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY>)) : YART_ANY(k_wf_shadow_fast<TRAV_FAST>); }
+AnyKernel extendGeneral(bool retry) { return retry ? YART_ANY(k_wf_extend<true>) : YART_ANY(k_wf_extend<false>); }
+AnyKernel shadowGeneral(bool retry) { return retry ? YART_ANY(k_wf_shadow<true>) : YART_ANY(k_wf_shadow<false>); }
+#elif YART_TU == 4
+AnyKernel shade(bool sort, bool fit, bool env1) {
+  return sort ? (env1 ? YART_ANY((k_wf_shade<true, true, true>)) : fit ? YART_ANY((k_wf_shade<true, true, false>)) : YART_ANY((k_wf_shade<true, false, false>)))
+              : (env1 ? YART_ANY((k_wf_shade<false, true, true>)) : fit ? YART_ANY((k_wf_shade<false, true, false>)) : YART_ANY((k_wf_shade<false, false, false>)));
+}
+#if defined(YART_SHADE_REGIONS)
+void shadeRegionsTake(unsigned long long* v48) {          // (measurement builds: the kernel's region counters live in this unit)
+  (void)hipMemcpyFromSymbol(v48, HIP_SYMBOL(g_shadeRegion), 48 * sizeof(unsigned long long));
+  const unsigned long long zero[48] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shadeRegion), zero, sizeof(zero));
+}
+#endif
+#endif
+#undef YART_PICK_LEAN
+#undef YART_ANY
+#if defined(YART_COUNT_TRAVERSAL)
+// (instrumented build: every unit tallies the texel bytes of ITS kernels' lookups; unit 0 sums them)
+#define YART_CAT2(a, b) a##b
+#define YART_CAT(a, b) YART_CAT2(a, b)
+void YART_CAT(texTapReset, YART_TU)() { const unsigned long long zero = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_texTapBytes), &zero, sizeof(zero)); }
+unsigned long long YART_CAT(texTapRead, YART_TU)() { unsigned long long v = 0; (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_texTapBytes), sizeof(v)); return v; }
+#endif
+}}  // namespace yart_hip::tu
+
+#else  // YART_TU == 0: everything below
+
+}  // namespace
+namespace yart_hip { namespace tu {
+typedef void (*AnyKernel)();
+AnyKernel extendLean(int nodesForm, bool ident);
+AnyKernel shadowLean(int nodesForm, bool ident);
+AnyKernel extendRetry(int nodesForm);
+AnyKernel shadowRetry(int nodesForm);
+AnyKernel extendFast(bool ident);
+AnyKernel shadowFast(bool ident);
+AnyKernel extendGeneral(bool retry);
+AnyKernel shadowGeneral(bool retry);
+AnyKernel shade(bool sort, bool fit, bool env1);
+#if defined(YART_SHADE_REGIONS)
+void shadeRegionsTake(unsigned long long* v48);
+#endif
+#if defined(YART_COUNT_TRAVERSAL)
+void texTapReset1(); void texTapReset2(); void texTapReset3(); void texTapReset4();
+unsigned long long texTapRead1(); unsigned long long texTapRead2(); unsigned long long texTapRead3(); unsigned long long texTapRead4();
+#endif
+}}
+namespace {
+typedef void (*WfKernelFn)(WfArgs);
+inline WfKernelFn wfKernel(yart_hip::tu::AnyKernel k) { return reinterpret_cast<WfKernelFn>(k); }
 
 // ---------------------------------------------------------------------------------------
 // host side
@@ -593,7 +687,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   HIP_CHECK(hipMemsetAsync(s.pathsLog.p, 0, 16 * sizeof(unsigned long long), stream));
   HIP_CHECK(hipMemsetAsync(s.counters.p, 0, kNumCounters * sizeof(unsigned long long), stream));
 #if defined(YART_COUNT_TRAVERSAL)
-  { const unsigned long long zero = 0; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_texTapBytes), &zero, sizeof(zero))); }
+  { const unsigned long long zero = 0; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_texTapBytes), &zero, sizeof(zero))); tu::texTapReset1(); tu::texTapReset2(); tu::texTapReset3(); tu::texTapReset4(); }
 #endif
 
   // lean traversal kernels when the scene allows them (every node transform chain the identity ->
@@ -610,37 +704,31 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   const bool tlasOk = s.dev.nTlas != 0u && s.host.nodes.size() <= 16384u && !(effFlags & (262144u | 65536u));
   const bool leanLds = !chunked && s.host.nodes.size() <= kLeanSceneNodes && s.host.meshes.size() <= kLeanSceneNodes;
   const int nodesForm = !chunked ? (leanLds ? 4 : 0) : tlasOk ? 3 : ((effFlags & 65536u) || s.host.nodes.size() >= kLeanWalkNodes) ? 2 : 1;
-#define YART_PICK_LEAN(KERNEL, M)                                                                                             \
-  (nodesForm == 4 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 4> : KERNEL<(M), 4>)                                                 \
-   : nodesForm == 3 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 3> : KERNEL<(M), 3>)                                               \
-   : nodesForm == 2 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 2> : KERNEL<(M), 2>)                                               \
-   : nodesForm == 1 ? (ident ? KERNEL<(M) | TRAV_IDENTITY, 1> : KERNEL<(M), 1>) : (ident ? KERNEL<(M) | TRAV_IDENTITY, 0> : KERNEL<(M), 0>))
   auto pickExtend = [&]() -> void (*)(WfArgs) {
-    if (!refill) return ident ? k_wf_extend_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_extend_fast<TRAV_FAST>;
-    return YART_PICK_LEAN(k_wf_extend_lean, TRAV_FAST);
+    if (!refill) return wfKernel(tu::extendFast(ident));
+    return wfKernel(tu::extendLean(nodesForm, ident));
   };
   auto pickShadow = [&]() -> void (*)(WfArgs) {
-    if (!refill) return ident ? k_wf_shadow_fast<TRAV_FAST | TRAV_IDENTITY> : k_wf_shadow_fast<TRAV_FAST>;
-    return YART_PICK_LEAN(k_wf_shadow_lean, TRAV_FAST);
+    if (!refill) return wfKernel(tu::shadowFast(ident));
+    return wfKernel(tu::shadowLean(nodesForm, ident));
   };
-#undef YART_PICK_LEAN
   auto kExtendFast = pickExtend();
   auto kShadowFast = pickShadow();
-  auto kRetryE = nodesForm == 4 ? k_wf_extend_retry_lean<4> : nodesForm == 3 ? k_wf_extend_retry_lean<3> : nodesForm == 2 ? k_wf_extend_retry_lean<2> : nodesForm == 1 ? k_wf_extend_retry_lean<1> : k_wf_extend_retry_lean<0>;
-  auto kRetryS = nodesForm == 4 ? k_wf_shadow_retry_lean<4> : nodesForm == 3 ? k_wf_shadow_retry_lean<3> : nodesForm == 2 ? k_wf_shadow_retry_lean<2> : nodesForm == 1 ? k_wf_shadow_retry_lean<1> : k_wf_shadow_retry_lean<0>;
+  auto kRetryE = wfKernel(tu::extendRetry(nodesForm));
+  auto kRetryS = wfKernel(tu::shadowRetry(nodesForm));
+  auto kExtendGen = wfKernel(tu::extendGeneral(false)), kExtendGenRetry = wfKernel(tu::extendGeneral(true));
+  auto kShadowGen = wfKernel(tu::shadowGeneral(false)), kShadowGenRetry = wfKernel(tu::shadowGeneral(true));
   const int gridMega = persistentGrid(s, reinterpret_cast<const void*>(k_render_mega), 3);
   const int gridExtendFast = persistentGrid(s, reinterpret_cast<const void*>(kExtendFast), 8);
   const int gridShadowFast = persistentGrid(s, reinterpret_cast<const void*>(kShadowFast), 8);
-  const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(k_wf_extend<false>), 8);
-  const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(k_wf_shadow<false>), 8);
+  const int gridExtend = persistentGrid(s, reinterpret_cast<const void*>(kExtendGen), 8);
+  const int gridShadow = persistentGrid(s, reinterpret_cast<const void*>(kShadowGen), 8);
   // the shade kernel's LDS copies of the scene's small tables: FIT when the sampler tables are in use (below) and every table fits its slot
   const bool samplerTables = !mega && !(p.flags & YART_FLAG_DIRECT_SAMPLER) && nPix > 0 && uint64_t(p.samples) <= (1ull << rc.sampler.log2spp);
   const bool shadeFit = samplerTables && s.dev.nMaterials <= kShadeMatSlots && s.dev.nTextures <= kShadeTexSlots && s.dev.nLights <= kShadeLightSlots &&
                         s.dev.nEnvs <= kShadeEnvSlots && s.dev.nNodes <= kShadeNodeSlots && s.dev.nInfinite <= kShadeLightSlots;
   const bool envOnly = shadeFit && s.dev.nArea == 0u && s.dev.nInfinite == 1u && s.dev.nLights == 1u;    // (variant of the FIT kernels only)
-  auto kShade = (effFlags & YART_FLAG_SHADE_SORT)
-                    ? (envOnly ? k_wf_shade<true, true, true> : shadeFit ? k_wf_shade<true, true, false> : k_wf_shade<true, false, false>)
-                    : (envOnly ? k_wf_shade<false, true, true> : shadeFit ? k_wf_shade<false, true, false> : k_wf_shade<false, false, false>);
+  auto kShade = wfKernel(tu::shade((effFlags & YART_FLAG_SHADE_SORT) != 0, shadeFit, envOnly));
   const int gridShade = persistentGrid(s, reinterpret_cast<const void*>(kShade), 8, kShadeBlock);
   const int gridRetryE = persistentGrid(s, reinterpret_cast<const void*>(kRetryE), 8);
   const int gridRetryS = persistentGrid(s, reinterpret_cast<const void*>(kRetryS), 8);
@@ -838,13 +926,13 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           }
           tExtend.begin(stream);
           if (general) {
-            hipLaunchKernelGGL(k_wf_extend<false>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(kExtendGen, dim3(gridExtend), dim3(kBlock), 0, stream, a);
           } else {
             tLean.begin(stream);
             hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
             tLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryE, dim3(gridRetryE), dim3(kBlock), 0, stream, a);
-            else hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(kExtendGenRetry, dim3(gridExtend), dim3(kBlock), 0, stream, a);
             hipLaunchKernelGGL(k_wf_reset_retry, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
           }
           HIP_CHECK(hipGetLastError());
@@ -857,13 +945,13 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           tShade.end(stream);
           tConnect.begin(stream);
           if (general) {
-            hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(kShadowGen, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           } else {
             tShadowLean.begin(stream);
             hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
             tShadowLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryS, dim3(gridRetryS), dim3(kBlock), 0, stream, a);
-            else hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(kShadowGenRetry, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           }
           HIP_CHECK(hipGetLastError());
           tConnect.end(stream);
@@ -919,13 +1007,13 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           TraceRange rgExtend("yart:extend", stream);
           tExtend.begin(stream);
           if (general) {
-            hipLaunchKernelGGL(k_wf_extend<false>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(kExtendGen, dim3(gridExtend), dim3(kBlock), 0, stream, a);
           } else {
             tLean.begin(stream);
             hipLaunchKernelGGL(kExtendFast, dim3(gridExtendFast), dim3(kBlock), 0, stream, a);
             tLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryE, dim3(gridRetryE), dim3(kBlock), 0, stream, a);
-            else hipLaunchKernelGGL(k_wf_extend<true>, dim3(gridExtend), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(kExtendGenRetry, dim3(gridExtend), dim3(kBlock), 0, stream, a);
             hipLaunchKernelGGL(k_wf_reset_retry, dim3(1), dim3(64), 0, stream, s.wfCounters.p);
           }
           HIP_CHECK(hipGetLastError());
@@ -942,13 +1030,13 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
           TraceRange rgShadow("yart:shadow", stream);
           tConnect.begin(stream);
           if (general) {
-            hipLaunchKernelGGL(k_wf_shadow<false>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
+            hipLaunchKernelGGL(kShadowGen, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           } else {
             tShadowLean.begin(stream);
             hipLaunchKernelGGL(kShadowFast, dim3(gridShadowFast), dim3(kBlock), 0, stream, a);
             tShadowLean.end(stream);
             if (refill) hipLaunchKernelGGL(kRetryS, dim3(gridRetryS), dim3(kBlock), 0, stream, a);
-            else hipLaunchKernelGGL(k_wf_shadow<true>, dim3(gridShadow), dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL(kShadowGenRetry, dim3(gridShadow), dim3(kBlock), 0, stream, a);
           }
           HIP_CHECK(hipGetLastError());
           tConnect.end(stream);
@@ -1044,6 +1132,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     {
       unsigned long long tb = 0;
       HIP_CHECK(hipMemcpyFromSymbol(&tb, HIP_SYMBOL(g_texTapBytes), sizeof(tb)));
+      tb += tu::texTapRead1() + tu::texTapRead2() + tu::texTapRead3() + tu::texTapRead4();
       stats->texture_tap_bytes = tb;
     }
 #endif
@@ -1499,10 +1588,8 @@ int yart_hip_debug_shade_regions(uint64_t* out48) {
   return guarded([&] {
     require(out48 != nullptr, "null pointer");
     unsigned long long v[3 * 16];
-    HIP_CHECK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_shadeRegion), sizeof(v)));
+    tu::shadeRegionsTake(v);
     for (int i = 0; i < 48; i++) out48[i] = v[i];
-    const unsigned long long zero[3 * 16] = {0};
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_shadeRegion), zero, sizeof(zero)));
   });
 #else
   (void)out48;
@@ -1569,3 +1656,4 @@ int yart_hip_bvh_build_host(const float* positions, uint32_t n_verts, const uint
 }
 
 }  // extern "C"
+#endif  // YART_TU == 0

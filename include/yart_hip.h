@@ -131,8 +131,8 @@ typedef struct YartRenderParams {
   uint32_t shard_tile;
   /* Upper bound on the (pixel, sample) paths per batch; 0 = 2^28 (a fixed number: the memory a render holds does not depend on
    * what happens to be free on the device; only a device that cannot hold the batch renders smaller ones). A wave is rendered
-   * batch by batch over this rank's pixels in tile order, every batch through all bounces and the estimator: 287 bytes per path
-   * of the batch (path state, queues, per-sample radiance, the compacted states of the late bounces). A smaller batch means
+   * batch by batch over this rank's pixels in tile order, every batch through all bounces and the estimator: 251 bytes per path
+   * of the batch (path state, queues, per-sample radiance, the compacted state of the late bounces). A smaller batch means
    * finished tiles arrive earlier (yart_hip_render_tiles) and less memory is held, at ~10 ms per batch on an MI355X (the C3 frame
    * of 531 M paths: +1.4 % in 2 batches, +4.5 % in 4, +19 % in 16). The frame does not depend on it. */
   uint32_t max_batch_paths;

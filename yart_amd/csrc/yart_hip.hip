@@ -59,7 +59,7 @@ constexpr int kBlock = 256;            // 4 waves per workgroup
 constexpr int kLdsStack = 24;          // traversal stack entries kept in LDS per lane (8 B each)
 constexpr int kSpillDepth = int(kRefStackDepth) - kLdsStack;
 constexpr int kSpillDepthMax = int(kRefStackDepth);   // spill area sized for the shallowest LDS stack
-constexpr uint64_t kDefaultBatchPaths = 1ull << 28;   // YartRenderParams::max_batch_paths = 0: 268 M paths (batch-synchronous: 77 GB; path pool: 4.3 GB of per-sample records)
+constexpr uint64_t kDefaultBatchPaths = 1ull << 28;   // YartRenderParams::max_batch_paths = 0: 268 M paths (batch-synchronous: 67 GB; path pool: 4.3 GB of per-sample records)
 constexpr uint64_t kDefaultPoolPaths = 1ull << 25;    // YartRenderParams::pool_paths = 0: 33.5 M slots, 5.6 GB
 constexpr int kPoolLag = 4;                            // the host looks at the counters of the round before the previous one (ring of 4)
 constexpr int kNumCounters = 32;       // [0] rays, [1..4] instrumented tallies, [8..31] debug statistics
@@ -461,7 +461,7 @@ struct YartScene {
   std::vector<unsigned long long> tileRaysHost;
   DevBuf<uint64_t> spill; DevBuf<float> hdr; DevBuf<uint32_t> probeIn; DevBuf<float> probeOut;
   DevBuf<f4> wf[9];                        // wavefront path state (wavefront.hpp::WfState)
-  DevBuf<f4> wfTail[2][9];                 // compacted states of the late bounces (1/2 and 1/4 of the batch)
+  DevBuf<f4> wfTail[1][9];                 // compacted state of the late bounces (1/2 of the batch; the second one is the batch-sized state itself)
   DevBuf<uint32_t> wfTailMap[2];
   DevBuf<WfDyn> wfDyn;
   DevBuf<unsigned long long> pathsLog;     // paths entering bounce b, summed over the batches of a render (YartStats::paths_at_bounce)
@@ -746,7 +746,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
   // Batch = the pixels (x all samples of a wave) rendered together: max_batch_paths, by default kDefaultBatchPaths — a fixed
   // number, no longer a share of the free device memory (round 3 sized ONE batch to 60 % of it: 150 GB for the C3 frame); only if
   // that does not fit the device is it cut down to what does. The default pipeline is batch-synchronous: one slot per path of the
-  // batch (287 bytes with the compacted tail states), every bounce one launch per stage over the paths still alive. What a smaller
+  // batch (251 bytes with the compacted tail state), every bounce one launch per stage over the paths still alive. What a smaller
   // batch costs (profiles/r4_ab_path_pool.txt): ~10 ms per batch of any size — the tail of every launch, when the GPU waits for
   // the slowest rays of the last waves — so the C3 frame in 2 / 4 / 8 / 16 batches is 1.4 / 4.5 / 9.7 / 19 % slower than in one.
   // YART_FLAG_PATH_POOL: the batch runs through a POOL of pool_paths slots with path regeneration instead (168 bytes per slot +
@@ -771,10 +771,10 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     held += uint64_t(s.smpEntries.n) * 8;      // the sampler tables of the previous render stay allocated
     if (std::getenv("YART_FAKE_FREE_MB")) held = 0;
     // what grows with the batch: 9 x 16 B of path state + 4 queue words + 16 B of radiance = 176 B per path; with compaction two
-    // tail states of 1/2 and 1/4 of the batch (9 x 16 B + a slot map word each) = 111 B more; the resume records of an eighth of
+    // a tail state of 1/2 of the batch (9 x 16 B + a slot map word) and a slot map of 1/4 = 75 B more; the resume records of an eighth of
     // the paths (kResumeWords x 16 B each = 24 B per path). What does not: the sampler tables (8 B x dims per PIXEL of the rank),
     // the resume records' per-wave ranges and the traversal spill area — taken off the budget first.
-    const uint64_t perPath = (compact ? 287 : 176) + ((p.flags & YART_FLAG_NO_RESUME) ? 0 : (kResumeWords * 16 + 7) / 8);
+    const uint64_t perPath = (compact ? 251 : 176) + ((p.flags & YART_FLAG_NO_RESUME) ? 0 : (kResumeWords * 16 + 7) / 8);
     const uint64_t dimsEst = std::min<uint32_t>(256u, (4u + 8u * p.max_depth + 16u + 7u) & ~7u);
     const uint64_t fixedB = uint64_t(nPix) * dimsEst * 8 + uint64_t(gridMax) * kBlock * (kResumeWords * 16 + uint64_t(kSpillDepthMax) * 8);
     const uint64_t budget = (uint64_t(freeB) + held) * 8 / 10;
@@ -811,11 +811,12 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
     }
     for (auto& b : s.wf) b.ensure(np);
     if (compact) {
-      for (int t = 0; t < 2; t++) {
-        const size_t cap = np / (t == 0 ? 2 : 4) + 64;
-        for (auto& b : s.wfTail[t]) b.ensure(cap);
-        s.wfTailMap[t].ensure(cap);
-      }
+      // Two dense "tail" states take the survivors in turn: the first is an array set of half the batch; the second is the BATCH-SIZED
+      // state itself — by the time a second compaction happens the paths live in the first tail and the large arrays hold nothing
+      // that is still read, so the survivors go back to their front (round 5: 36 B per path less than a third array set).
+      for (auto& b : s.wfTail[0]) b.ensure(np / 2 + 64);
+      s.wfTailMap[0].ensure(np / 2 + 64);
+      s.wfTailMap[1].ensure(np / 4 + 64);
       s.wfDyn.ensure(1);
     }
     s.qA.ensure(np); s.qB.ensure(np); s.qS.ensure(np); s.qR.ensure(np); s.wfCounters.ensure(WC_COUNT);
@@ -983,7 +984,7 @@ bool renderToDevice(YartScene& s, const YartCameraDesc& camDesc, const YartRende
         if (compact) {
           for (int t = 0; t < 2; t++) {
             f4** f = &a.tail[t].ray0;                  // the nine pointers of WfState, in declaration order
-            for (int k = 0; k < 9; k++) f[k] = s.wfTail[t][k].p;
+            for (int k = 0; k < 9; k++) f[k] = t == 0 ? s.wfTail[0][k].p : s.wf[k].p;      // (second tail: the batch-sized state, see above)
             a.tailMap[t] = s.wfTailMap[t].p;
             a.tailCap[t] = a.nPaths / (t == 0 ? 2u : 4u);
           }

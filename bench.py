@@ -326,7 +326,7 @@ def secondary_workloads(args, api, torch, np, headline_scene, headline_p, device
     out, ok = [], True
     specs = [
         # (name, BASELINE config, scene factory, pipeline flags, warm-up, steps, parity spp)
-        ("mclaren_class", "configs[4]", lambda: scenes.mclaren_class(3840, 2160, 512, 8, detail=1.0), 0, 1, 1, 1),
+        ("mclaren_class", "configs[4]", lambda: scenes.mclaren_class(3840, 2160, 512, 8, detail=1.0), 0, 1, 2, 1),
         ("sponza_class", "configs[3]", lambda: (headline_scene, dict(headline_p, spp=1024)), 0, 1, 2, 4),      # the headline's scene and camera at 1024 spp
         ("cornell", "configs[1]", lambda: scenes.cornell(512, 512, 64, 4), 1, 2, 5, 64),
     ]

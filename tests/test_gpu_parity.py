@@ -546,3 +546,34 @@ def test_batch_clamp_on_a_small_device_budget(api, pipeline, monkeypatch):
     monkeypatch.delenv("YART_FAKE_FREE_MB")
     bit_identical_or_drift(img, ref, f"cornell/{pipeline} under a 48 MB budget")
     scene.close()
+
+
+def test_render_stages_are_roctx_ranges(api, tmp_path):
+    """SURVEY §5 "tracing": the stages of a render are roctx ranges (csrc/trace_ranges.hpp; the library is bound by name, YART_ROCTX_LIB
+    names it). With a logging stand-in (tests/fake_roctx) a two-wave render must open `yart:render` once, inside it per wave `generate`
+    and per bounce `bounce k` > `extend`, `shade`, `shadow` (+ `roulette`, `compact` from the second bounce on), then `gmon_blend`;
+    every push has its pop, nesting never exceeds three levels — and the frame is still the golden one. Run in a child process: the
+    library is bound once per process."""
+    import sys
+    from tests.conftest import ROOT
+    so = str(tmp_path / "libfake_roctx.so")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", so, os.path.join(ROOT, "tests", "fake_roctx", "fake_roctx.c")], check=True)
+    log = str(tmp_path / "roctx.log")
+    base = os.path.join(GOLDEN, "cornell_waves")
+    code = (f"import sys; sys.path.insert(0, {ROOT!r})\n"
+            "import numpy as np\nfrom yart_amd import api\nfrom tests.paramfile import load_params\n"
+            f"base = {base!r}\np = load_params(base + '.txt')\nds = api.DeviceScene(base + '.yscn', device=0)\nimg, st = ds.render(p)\n"
+            "ref = np.fromfile(base + '.f32', np.float32).reshape(img.shape)\nassert np.array_equal(img.view(np.uint32), ref.view(np.uint32))\nds.close()\n")
+    env = dict(os.environ, YART_ROCTX_LIB=so, FAKE_ROCTX_LOG=log)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln.split(" ", 2) for ln in open(log).read().splitlines()]
+    pushes = [ln[2] for ln in lines if ln[0] == "push"]
+    assert sum(ln[0] == "push" for ln in lines) == sum(ln[0] == "pop" for ln in lines) and max(int(ln[1]) for ln in lines) <= 3
+    assert pushes.count("yart:render") == 1 and pushes[0] == "yart:render" and lines[-1][0] == "pop" and lines[-1][1] == "0"
+    depth = load_params(base + ".txt")["depth"]
+    assert pushes.count("yart:sampler_tables") == 1 and pushes.count("yart:generate") == 2 and pushes.count("yart:gmon_blend") == 2   # two waves
+    for k in range(depth):
+        assert pushes.count(f"yart:bounce {k}") == 2
+    assert pushes.count("yart:extend") == pushes.count("yart:shade") == pushes.count("yart:shadow") == 2 * depth
+    assert pushes.count("yart:roulette") == 2 * max(0, depth - 2) and pushes.count("yart:compact") == 2 * max(0, depth - 2)

@@ -33,6 +33,9 @@ constexpr uint32_t kLeanRefill = YART_LEAN_REFILL;      // refill when at least 
 #define YART_LEAN_INNER_MIN 12
 #endif
 constexpr uint32_t kLeanInnerMin = YART_LEAN_INNER_MIN;
+#ifndef YART_RETRY_REFILL
+#define YART_RETRY_REFILL 52
+#endif
 #ifndef YART_LEAN_CHUNK_MAX
 #define YART_LEAN_CHUNK_MAX 256u
 #endif   // leave the inner loop when fewer lanes than this still step
@@ -73,7 +76,10 @@ __device__ __forceinline__ void traceLean(const SceneDev& sc, const SamplerConfi
                                           uint32_t count, uint32_t* cursor, Fetch fetch, Commit commit,
                                           Retry retry, WfTally& tally) {
   constexpr bool kFast = (MODE & TRAV_FAST) != 0;             // else: the general walk (alpha tests, NEE attenuation)
-  constexpr uint32_t kRefill = kLeanRefill;
+  // the general walk over the retry queue (resumed rays: they start at a leaf and their REMAINING walks differ far more than whole
+  // walks do) may take new rays earlier than the lean kernels: YART_RETRY_REFILL (profiles/r5_retry_refill.txt)
+  constexpr uint32_t kRefill = kFast ? kLeanRefill : uint32_t(YART_RETRY_REFILL);
+  constexpr uint32_t kRefillHere = kRefill;
   Sampler smp; smp.morton = 0; smp.dim = 0; smp.pix = 0;
   f3 attenuation = mk3(1.0f);
   const uint32_t lane = threadIdx.x & 63u;

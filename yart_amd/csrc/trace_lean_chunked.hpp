@@ -201,6 +201,7 @@ __device__ __forceinline__ void traceLeanChunked(const SceneDev& sc, const Sampl
     if (__ballot(has && needMask) == 0ull) break;               // a lane moved on to the next node chunk: mask, walk again
     }
 
+constexpr uint32_t kRefillHere = kLeanRefill;
 #include "trace_lean_bvh2.inc"
   }
 #undef LEAN_VISIT

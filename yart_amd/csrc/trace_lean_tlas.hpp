@@ -227,6 +227,7 @@ __device__ __forceinline__ void traceLeanTlas(const SceneDev& sc, const SamplerC
     if (__ballot(has && needMask) == 0ull) break;               // a lane moved on to the next node chunk: mask, walk again
     }
 
+constexpr uint32_t kRefillHere = kLeanRefill;
 #include "trace_lean_bvh2.inc"
   }
   clearBits();                                                  // (the buffer is all zero between launches)

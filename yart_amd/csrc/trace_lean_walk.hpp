@@ -168,6 +168,7 @@ __device__ __forceinline__ void traceLeanWalk(const SceneDev& sc, const SamplerC
       }
     }
 
+constexpr uint32_t kRefillHere = kLeanRefill;
 #include "trace_lean_bvh2.inc"
   }
 #undef LEAN_VISIT
